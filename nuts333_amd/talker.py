@@ -1,0 +1,153 @@
+"""Boot / stop a talker process (the reference build or our restatement) in a scratch tree.
+
+Launch rules, each a measured reference behaviour:
+
+* the talker daemonises itself -- the parent forks, sleeps one second and exits
+  (``nuts333.c:79-83``) -- so the process we start is not the one that serves; the
+  daemon's PID is taken from the boot line the child appends to ``./syslog``
+  (``nuts333.c:86-87``, ``1434-1444``);
+* stdout/stderr go to a file, never a pipe (the daemon keeps the descriptors open);
+* it is stopped with SIGKILL once every client socket is closed: the SIGTERM path runs
+  ``talker_shutdown`` which walks freed list nodes (``nuts333.c:4044``).
+"""
+from __future__ import annotations
+
+import os
+import re
+import signal
+import socket
+import subprocess
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+REF_BINARY = REPO / "oracle" / "_ref" / "nuts333"
+REF_BINARY_O0 = REPO / "oracle" / "_ref" / "nuts333_O0"
+PORT_BINARY = REPO / "oracle" / "_build" / "talker_port"
+
+_BOOT_RE = re.compile(r"Booted successfully with PID (\d+)")
+
+
+def free_ports(n: int = 3) -> list[int]:
+    """n distinct currently-free loopback TCP ports."""
+    socks, ports = [], []
+    try:
+        for _ in range(n):
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            socks.append(s)
+            ports.append(s.getsockname()[1])
+    finally:
+        for s in socks:
+            s.close()
+    return ports
+
+
+class Talker:
+    def __init__(self, binary: os.PathLike | str, root: os.PathLike | str, config_name: str = "config",
+                 cpu: int | None = None, tz: str = "UTC"):
+        self.binary = Path(binary)
+        self.root = Path(root)
+        self.config_name = config_name
+        self.cpu = cpu
+        self.tz = tz
+        self.pid: int | None = None
+
+    # -- lifecycle -------------------------------------------------------------------
+    def start(self, timeout: float = 15.0) -> int:
+        if not self.binary.exists():
+            raise FileNotFoundError(
+                f"{self.binary} is not built; run `make -C oracle` (reference) or `python -c "
+                "'import __graft_entry__ as g; g.build()'`")
+        syslog = self.root / "syslog"
+        if syslog.exists():
+            syslog.unlink()
+        env = dict(os.environ, TZ=self.tz)
+        out = open(self.root / "boot.log", "wb")
+
+        def _pre():
+            os.setsid()
+            if self.cpu is not None:
+                try:
+                    os.sched_setaffinity(0, {self.cpu})
+                except OSError:
+                    pass
+
+        try:
+            launcher = subprocess.Popen([str(self.binary), self.config_name], cwd=self.root, stdin=subprocess.DEVNULL,
+                                        stdout=out, stderr=subprocess.STDOUT, env=env, preexec_fn=_pre)
+        finally:
+            out.close()
+        deadline = time.monotonic() + timeout
+        rc = None
+        while time.monotonic() < deadline:
+            if syslog.exists():
+                m = _BOOT_RE.search(syslog.read_text(errors="replace"))
+                if m:
+                    self.pid = int(m.group(1))
+                    break
+            rc = launcher.poll()
+            if rc not in (None, 0):
+                break
+            time.sleep(0.02)
+        if self.pid is None:
+            launcher.kill() if launcher.poll() is None else None
+            log = (self.root / "boot.log").read_text(errors="replace")
+            raise RuntimeError(f"talker did not boot (launcher rc={rc}):\n{log}")
+        # reap the launcher (it exits one second after fork; do not wait for it inline)
+        self._launcher = launcher
+        return self.pid
+
+    def alive(self) -> bool:
+        if self.pid is None:
+            return False
+        try:
+            os.kill(self.pid, 0)
+        except ProcessLookupError:
+            return False
+        try:
+            stat = Path(f"/proc/{self.pid}/stat").read_text()
+            return stat.rsplit(")", 1)[1].split()[0] != "Z"
+        except OSError:
+            return False
+
+    def stop(self) -> None:
+        if self.pid is not None:
+            try:
+                os.kill(self.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            for _ in range(200):
+                if not self.alive():
+                    break
+                time.sleep(0.01)
+            self.pid = None
+        launcher = getattr(self, "_launcher", None)
+        if launcher is not None:
+            try:
+                launcher.wait(timeout=3)
+            except subprocess.TimeoutExpired:
+                launcher.kill()
+                launcher.wait()
+            self._launcher = None
+
+    def __enter__(self) -> "Talker":
+        self.start()
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.stop()
+
+    # -- /proc sampling --------------------------------------------------------------
+    def cpu_times(self) -> tuple[float, float]:
+        """(user_s, sys_s) of the daemon from /proc/<pid>/stat fields 14/15."""
+        stat = Path(f"/proc/{self.pid}/stat").read_text()
+        f = stat.rsplit(")", 1)[1].split()
+        hz = os.sysconf("SC_CLK_TCK")
+        return int(f[11]) / hz, int(f[12]) / hz
+
+    def rss_peak_kb(self) -> int:
+        for line in Path(f"/proc/{self.pid}/status").read_text().splitlines():
+            if line.startswith("VmHWM:"):
+                return int(line.split()[1])
+        return 0

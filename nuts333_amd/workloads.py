@@ -1,0 +1,323 @@
+"""The five BASELINE.json configurations as concrete, deterministic workloads.
+
+Each ``configN`` function provisions a scratch tree (``provision.py``), boots a talker
+(``talker.py``), writes a spec for the compiled load generator (``loadgen/loadgen.c``),
+runs it and returns one result dict.  The definitions follow SURVEY.md section 8(d):
+
+1. 1 client ``Fred`` (GOD), ``.go lounge``, closed-loop ``say``             -- plumbing
+2. 10 level-1 clients left in ``drive``; client 0 says M lines               -- 9 recipients/line
+3. 100 clients, 20 per room over the 5 rooms; seeded (333) mix of
+   70 % say / 20 % .shout / 10 % .tell, every client sends                   -- mixed
+4. 1000 level-1 clients in ``drive``; client 0 ``.shout``s M lines            -- 999 recipients/line
+5. two talkers joined by a netlink; 10 locals each, 5 of talker1's users
+   ``.go talker2``; one remote and one local user ``.shout``                  -- MSG/EMSG relay
+
+The metric (BASELINE.json) is *delivered lines per second* = lines written to recipients
+other than the sender, divided by the wall time of the timed phase; the sender's own
+acknowledgement lines (``You say: ...``) are counted separately as ``acks``.
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import shutil
+import subprocess
+import tempfile
+from pathlib import Path
+from typing import Callable, Sequence
+
+from . import provision as pv
+from .talker import PORT_BINARY, REF_BINARY, Talker, free_ports
+
+HERE = Path(__file__).resolve().parent
+LOADGEN_SRC = HERE / "loadgen" / "loadgen.c"
+LOADGEN_BIN = HERE / "loadgen" / "loadgen"
+
+LOOK_END = r"has been set yet.\n\r"
+
+#: 54-byte payload with a 6-digit sequence number, no '~', no leading command
+#: character, none of the three filtered words (nuts333.h:275-277).
+PAYLOAD_FMT = "synthetic broadcast line {:06d} from the nuts333 bench"
+PAYLOAD_LEN = 54
+
+
+def payload(seq: int) -> str:
+    s = PAYLOAD_FMT.format(seq % 1_000_000)
+    assert len(s) == PAYLOAD_LEN, len(s)
+    return s
+
+
+def build_loadgen(force: bool = False) -> Path:
+    if force or not LOADGEN_BIN.exists() or LOADGEN_BIN.stat().st_mtime < LOADGEN_SRC.stat().st_mtime:
+        subprocess.run(["gcc", "-O2", "-Wall", "-Wextra", "-pthread", str(LOADGEN_SRC), "-o", str(LOADGEN_BIN)],
+                       check=True)
+    return LOADGEN_BIN
+
+
+def host_cpus() -> list[int]:
+    return sorted(os.sched_getaffinity(0))
+
+
+def pick_binary(kind: str = "auto") -> tuple[Path, str]:
+    """('reference' | 'port' | 'auto') -> (binary path, kind actually used)."""
+    if kind in ("reference", "auto") and REF_BINARY.exists():
+        return REF_BINARY, "reference"
+    if kind == "reference":
+        raise FileNotFoundError(f"{REF_BINARY} missing: build it with `make -C oracle ref` where /root/reference exists")
+    if PORT_BINARY.exists():
+        return PORT_BINARY, "port"
+    raise FileNotFoundError("neither oracle/_ref/nuts333 nor oracle/_build/talker_port is built; run __graft_entry__.build()")
+
+
+# --------------------------------------------------------------------------- spec / run
+class Spec:
+    def __init__(self) -> None:
+        self.clients: list[tuple[str, str, str, int]] = []
+        self.pre: list[tuple[int, str, str]] = []
+        self.lines: list[tuple[int, str]] = []
+        self.expect_lines = 0
+        self.expected_deliveries = 0
+        self.expected_per_client: list[int] = []
+
+    def add_client(self, name: str, port: int, host: str = "127.0.0.1", password: str = pv.PASSWORD) -> int:
+        self.clients.append((name, password, host, port))
+        self.expected_per_client.append(0)
+        return len(self.clients) - 1
+
+    def add_pre(self, idx: int, line: str, expect: str = LOOK_END) -> None:
+        self.pre.append((idx, expect, line))
+
+    def add_line(self, sender: int, text: str, recipients: Sequence[int]) -> None:
+        """One input line; ``recipients`` are the client indices that must receive one line each."""
+        assert "\n" not in text and "\t" not in text and len(text) < 900
+        self.lines.append((sender, text))
+        self.expected_per_client[sender] += 1          # the acknowledgement
+        for r in recipients:
+            assert r != sender
+            self.expected_per_client[r] += 1
+        self.expect_lines += 1 + len(recipients)
+        self.expected_deliveries += len(recipients)
+
+    def render(self, server_pids: Sequence[int], threads: int, cpus: Sequence[int], timeout_s: float,
+               login_window: int, spin: bool = True) -> str:
+        out = [f"threads {threads}", f"login_window {login_window}", f"timeout_s {timeout_s}",
+               f"expect_lines {self.expect_lines}", f"spin {int(spin)}"]
+        if cpus:
+            out.append("cpus " + ",".join(str(c) for c in cpus))
+        out += [f"server_pid {p}" for p in server_pids]
+        out += [f"client {n} {p} {h} {port}" for n, p, h, port in self.clients]
+        out += [f"pre {i} {e}\t{l}" for i, e, l in self.pre]
+        out += [f"line {i} {t}" for i, t in self.lines]
+        return "\n".join(out) + "\n"
+
+
+def run_spec(spec: Spec, talkers: Sequence[Talker], *, timeout_s: float = 600.0, pin: bool = True,
+             threads: int | None = None) -> dict:
+    build_loadgen()
+    cpus = host_cpus()
+    server_cpus = {t.cpu for t in talkers if t.cpu is not None}
+    client_cpus = [c for c in cpus if c not in server_cpus] if pin else []
+    if threads is None:
+        threads = max(1, min(len(client_cpus) or len(cpus) - 1 or 1, 14, len(spec.clients)))
+    # the talker listens with backlog 10 (nuts333.c:1189): keep concurrent logins below it
+    login_window = max(1, 8 // threads)
+    text = spec.render([t.pid for t in talkers], threads, client_cpus, timeout_s, login_window)
+    proc = subprocess.run([str(LOADGEN_BIN)], input=text.encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=timeout_s + 60)
+    try:
+        res = json.loads(proc.stdout.decode().strip().splitlines()[-1])
+    except (IndexError, json.JSONDecodeError):
+        raise RuntimeError(f"loadgen produced no result (rc={proc.returncode}): {proc.stderr.decode()[-2000:]}")
+    if proc.returncode != 0 or not res.get("ok"):
+        raise RuntimeError(f"loadgen failed (rc={proc.returncode}): {proc.stderr.decode()[-2000:]} {res}")
+    res["expected_deliveries"] = spec.expected_deliveries
+    res["per_client_exact"] = res.pop("per_client_lines") == spec.expected_per_client
+    res["exact"] = bool(res["per_client_exact"] and res["lines_total"] == spec.expect_lines
+                        and res["deliveries"] == spec.expected_deliveries)
+    return summarise(res)
+
+
+def summarise(res: dict) -> dict:
+    wall = res["wall_s"]
+    deliv = res["deliveries"]
+    res["delivered_lines_per_s"] = deliv / wall if wall > 0 else 0.0
+    res["input_lines_per_s"] = res["input_lines"] / wall if wall > 0 else 0.0
+    res["bytes_per_line"] = res["bytes_total"] / res["lines_total"] if res["lines_total"] else 0.0
+    for s in res["servers"]:
+        written = res["lines_total"]          # every line, acks included, costs the server one write_user
+        s["cpu_us_per_written_line"] = s["cpu_ns"] / 1e3 / written if written else 0.0
+        tot = s["utime_s"] + s["stime_s"]
+        s["user_frac"] = s["utime_s"] / tot if tot > 0 else None
+        s["busy_frac"] = s["cpu_ns"] / 1e9 / wall if wall > 0 else 0.0
+    return res
+
+
+# --------------------------------------------------------------------------- configs
+def _boot(root: Path, cfg: pv.TalkerConfig, accounts, binary: Path, cpu: int | None) -> Talker:
+    pv.write_tree(root, cfg, accounts)
+    t = Talker(binary, root, cpu=cpu)
+    t.start()
+    return t
+
+
+def _server_cpu(pin: bool, k: int = 0) -> int | None:
+    if not pin:
+        return None
+    cpus = host_cpus()
+    return cpus[k] if len(cpus) > k + 1 else None
+
+
+def _run_single(build: Callable[[Spec, int], None], accounts, *, binary: Path, pin: bool, workdir: Path | None,
+                timeout_s: float, max_users: int = 1100, colour: int = 0) -> dict:
+    tmp = Path(tempfile.mkdtemp(prefix="nuts333_", dir=workdir))
+    talker = None
+    try:
+        ports = free_ports(3)
+        cfg = pv.TalkerConfig(mainport=ports[0], wizport=ports[1], linkport=ports[2], max_users=max_users)
+        talker = _boot(tmp, cfg, accounts, binary, _server_cpu(pin))
+        spec = Spec()
+        build(spec, ports[0])
+        res = run_spec(spec, [talker], timeout_s=timeout_s, pin=pin)
+        res["server_rss_peak_kb"] = talker.rss_peak_kb()
+        res["server_alive_after"] = talker.alive()
+        return res
+    finally:
+        if talker is not None:
+            talker.stop()
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def config1(lines: int = 10_000, *, binary: Path, pin: bool = True, workdir=None, timeout_s: float = 300.0) -> dict:
+    """1 client, ``.go lounge``, closed-loop say; nobody else hears it (plumbing / latency)."""
+    accounts = [pv.Account("Fred", level=4, desc="the GOD account")]
+
+    def build(spec: Spec, port: int) -> None:
+        c = spec.add_client("Fred", port)
+        spec.add_pre(c, ".go lounge")          # GOD teleports (nuts333.c:4399-4404)
+        for i in range(lines):
+            spec.add_line(c, payload(i), [])
+
+    res = _run_single(build, accounts, binary=binary, pin=pin, workdir=workdir, timeout_s=timeout_s)
+    res["workload"] = f"config1: 1 client, {lines} say lines in lounge"
+    return res
+
+
+def config2(lines: int = 20_000, n: int = 10, *, colour: int = 0, all_send: bool = False, binary: Path,
+            pin: bool = True, workdir=None, timeout_s: float = 300.0) -> dict:
+    """n clients in ``drive``; client 0 (or everyone, ``all_send``) says ``lines`` lines."""
+    accounts = [pv.Account(pv.bot_name(i), level=1, colour=colour) for i in range(n)]
+
+    def build(spec: Spec, port: int) -> None:
+        ids = [spec.add_client(pv.bot_name(i), port) for i in range(n)]
+        senders = ids if all_send else ids[:1]
+        per = lines // len(senders)
+        for k in range(per):
+            for s in senders:
+                spec.add_line(s, payload(k), [r for r in ids if r != s])
+
+    res = _run_single(build, accounts, binary=binary, pin=pin, workdir=workdir, timeout_s=timeout_s, max_users=n + 10)
+    res["workload"] = f"config2: {n} clients in one room, {lines} say lines, {'all send' if all_send else 'client 0 sends'}, colour {colour}"
+    return res
+
+
+def config3(per_client: int = 200, n: int = 100, *, seed: int = 333, binary: Path, pin: bool = True, workdir=None,
+            timeout_s: float = 600.0) -> dict:
+    """n clients spread evenly over the 5 rooms; seeded 70/20/10 say/.shout/.tell mix from every client."""
+    rooms = [r.name for r in pv.DEFAULT_ROOMS]
+    room_of = [rooms[i % len(rooms)] for i in range(n)]
+    accounts = [pv.Account(pv.bot_name(i), level=2 if room_of[i] == "wizroom" else 1) for i in range(n)]
+    rng = random.Random(seed)
+
+    def build(spec: Spec, port: int) -> None:
+        ids = [spec.add_client(pv.bot_name(i), port) for i in range(n)]
+        for i in ids:
+            for hop in pv.WALKS[room_of[i]]:
+                spec.add_pre(i, f".go {hop}")
+        members = {r: [i for i in ids if room_of[i] == r] for r in rooms}
+        seq = 0
+        for _ in range(per_client):
+            for s in ids:
+                x = rng.random()
+                text = payload(seq); seq += 1
+                if x < 0.70:
+                    spec.add_line(s, text, [r for r in members[room_of[s]] if r != s])
+                elif x < 0.90:
+                    spec.add_line(s, ".shout " + text, [r for r in ids if r != s])
+                else:
+                    tgt = rng.choice([r for r in ids if r != s])
+                    spec.add_line(s, f".tell {pv.bot_name(tgt)} {text}", [tgt])
+
+    res = _run_single(build, accounts, binary=binary, pin=pin, workdir=workdir, timeout_s=timeout_s, max_users=n + 10)
+    res["workload"] = f"config3: {n} clients over 5 rooms, {per_client} lines each, 70/20/10 say/shout/tell, seed {seed}"
+    return res
+
+
+def config4(lines: int = 1000, n: int = 1000, *, colour: int = 0, binary: Path, pin: bool = True, workdir=None,
+            timeout_s: float = 900.0) -> dict:
+    """n clients in ``drive``; client 0 ``.shout``s ``lines`` lines (n-1 recipients each)."""
+    accounts = [pv.Account(pv.bot_name(i), level=1, colour=colour) for i in range(n)]
+
+    def build(spec: Spec, port: int) -> None:
+        ids = [spec.add_client(pv.bot_name(i), port) for i in range(n)]
+        for k in range(lines):
+            spec.add_line(ids[0], ".shout " + payload(k), ids[1:])
+
+    res = _run_single(build, accounts, binary=binary, pin=pin, workdir=workdir, timeout_s=timeout_s, max_users=n + 10)
+    res["workload"] = f"config4: {n} clients, client 0 shouts {lines} lines, colour {colour}"
+    return res
+
+
+def config5(lines: int = 1000, locals_each: int = 10, travellers: int = 5, *, binary: Path, pin: bool = True,
+            workdir=None, timeout_s: float = 300.0) -> dict:
+    """Two talkers joined by a netlink; a remote and a local user of talker2 shout concurrently."""
+    tmp = Path(tempfile.mkdtemp(prefix="nuts333_nl_", dir=workdir))
+    t1 = t2 = None
+    try:
+        p1, p2 = free_ports(3), free_ports(3)
+        names1 = [pv.bot_name(i) for i in range(locals_each)]
+        names2 = [pv.bot_name(locals_each + i) for i in range(locals_each)]
+        # talker2 accepts in its lounge (ACCEPT room); it must know talker1's site string as
+        # reverse-resolved by gethostbyaddr (nuts333.c:322, 2908-2909): list both spellings
+        cfg2 = pv.TalkerConfig(mainport=p2[0], wizport=p2[1], linkport=p2[2], verification="fred123x",
+                               sites=[pv.Site("talker1", "localhost", p1[2], "bloggs456x"),
+                                      pv.Site("talker1", "127.0.0.1", p1[2], "bloggs456x")])
+        rooms1 = tuple(pv.Room(r.label, r.name, r.links, r.access or ("PUB" if r.name == "drive" else ""),
+                               "CONNECT talker2" if r.name == "drive" else ("" if r.netlink == "ACCEPT" else r.netlink),
+                               r.description) for r in pv.DEFAULT_ROOMS)
+        cfg1 = pv.TalkerConfig(mainport=p1[0], wizport=p1[1], linkport=p1[2], verification="bloggs456x",
+                               auto_connect=True, rooms=rooms1,
+                               sites=[pv.Site("talker2", "127.0.0.1", p2[2], "fred123x")])
+        t2 = _boot(tmp / "t2", cfg2, [pv.Account(n) for n in names2], binary, _server_cpu(pin, 0))
+        t1 = _boot(tmp / "t1", cfg1, [pv.Account(n) for n in names1], binary, _server_cpu(pin, 1))
+        spec = Spec()
+        ids1 = [spec.add_client(n, p1[0]) for n in names1]
+        ids2 = [spec.add_client(n, p2[0]) for n in names2]
+        gone = ids1[:travellers]
+        for i in gone:
+            spec.add_pre(i, ".go talker2")        # TRANS -> GRANTED -> ACT look -> MSG frames back
+        on_t2 = ids2 + gone
+        remote_sender, local_sender = gone[0], ids2[0]
+        for k in range(lines):
+            for s in (remote_sender, local_sender):
+                spec.add_line(s, ".shout " + payload(k), [r for r in on_t2 if r != s])
+        res = run_spec(spec, [t1, t2], timeout_s=timeout_s, pin=pin, threads=2)
+        res["workload"] = (f"config5: 2 talkers, {locals_each} locals each, {travellers} of talker1's users on talker2, "
+                           f"1 remote + 1 local sender x {lines} shouts")
+        # every line that reaches a travelling user crossed the link as one MSG..EMSG frame (nuts333.c:1302-1305)
+        res["netlink_frames_t2_to_t1"] = (2 * lines) * (len(gone) - 1) + lines + lines   # deliveries + remote sender's acks
+        res["netlink_frames_t1_to_t2"] = lines                                            # ACT <name> .shout ...
+        res["servers_alive_after"] = [t1.alive(), t2.alive()]
+        return res
+    finally:
+        for t in (t1, t2):
+            if t is not None:
+                t.stop()
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def probe_write(nbytes: int = 67, count: int = 300_000) -> dict:
+    build_loadgen()
+    out = subprocess.run([str(LOADGEN_BIN), "--probe-write", str(nbytes), str(count)], check=True,
+                         stdout=subprocess.PIPE).stdout
+    return json.loads(out)
