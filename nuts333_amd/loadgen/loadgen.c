@@ -87,6 +87,9 @@ static int g_server_pids[MAX_SERVERS], g_nservers;
 static uint64_t g_expect_lines;
 static int g_cpus[256], g_ncpus;
 static int g_verbose;
+static int g_quickack = 1; /* re-arm TCP_QUICKACK after every read: the talker never sets TCP_NODELAY, so a second
+                              small write to the same socket waits (Nagle) for our ACK, which the kernel would
+                              otherwise delay by up to 40 ms -- that would time the delayed-ACK timer, not the talker */
 static int g_spin = 1;   /* busy-poll in the timed phase: a sleeping receiver would make the talker pay a
                             cross-CPU wake-up inside every write(2), which measures the scheduler, not the talker */
 
@@ -128,6 +131,7 @@ static void parse_spec(FILE *fp) {
         else if (!strncmp(line, "timeout_s ", 10)) g_timeout_s = atof(line + 10);
         else if (!strncmp(line, "verbose ", 8)) g_verbose = atoi(line + 8);
         else if (!strncmp(line, "spin ", 5)) g_spin = atoi(line + 5);
+        else if (!strncmp(line, "quickack ", 9)) g_quickack = atoi(line + 9);
         else if (!strncmp(line, "expect_lines ", 13)) g_expect_lines = strtoull(line + 13, NULL, 10);
         else if (!strncmp(line, "server_pid ", 11)) {
             if (g_nservers < MAX_SERVERS) g_server_pids[g_nservers++] = atoi(line + 11);
@@ -234,6 +238,7 @@ static void start_connect(struct worker *w, struct client *c) {
     /* blocking connect on loopback is immediate; the talker's listen backlog is 10
        (nuts333.c:1189) so the login window must stay below that */
     if (connect(c->fd, (struct sockaddr *)&sa, sizeof(sa)) < 0) { failf(c, "connect failed"); return; }
+    if (g_quickack) setsockopt(c->fd, IPPROTO_TCP, TCP_QUICKACK, &one, sizeof(one));
     int fl = fcntl(c->fd, F_GETFL, 0); fcntl(c->fd, F_SETFL, fl | O_NONBLOCK);
     struct epoll_event ev; ev.events = EPOLLIN; ev.data.ptr = c;
     if (epoll_ctl(w->epfd, EPOLL_CTL_ADD, c->fd, &ev) < 0) die("epoll_ctl");
@@ -363,6 +368,7 @@ static int drain_client(struct worker *w, struct client *c, char *rbuf, int runn
         if (errno == EAGAIN || errno == EWOULDBLOCK) break;
         failf(c, "recv failed"); return -1;
     }
+    if (g_quickack && total) { int one = 1; setsockopt(c->fd, IPPROTO_TCP, TCP_QUICKACK, &one, sizeof(one)); }
     return total;
 }
 
@@ -490,10 +496,74 @@ static int probe_write(int bytes, long count) {
     return 0;
 }
 
+
+/* K connected loopback pairs, one spinning reader draining all of them, one writer doing
+   nothing but write(2) of BYTES to each socket in turn: the floor of the reference's
+   fan-out loop (nuts333.c:1409-1428 -> 1363) with zero user-space work. */
+struct fan_arg { int epfd; atomic_int stop; atomic_ullong rx; };
+static void *fan_reader(void *arg) {
+    struct fan_arg *fa = arg; char *buf = malloc(RBUF); struct epoll_event evs[256];
+    while (!atomic_load(&fa->stop)) {
+        int n = epoll_wait(fa->epfd, evs, 256, 0);
+        for (int i = 0; i < n; i++) {
+            int fd = evs[i].data.fd;
+            ssize_t r; unsigned long long got = 0;
+            while ((r = recv(fd, buf, RBUF, MSG_DONTWAIT)) > 0) got += (unsigned long long)r;
+            atomic_fetch_add(&fa->rx, got);
+            int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_QUICKACK, &one, sizeof(one));
+        }
+    }
+    free(buf); return NULL;
+}
+
+static int probe_fanout(int bytes, int k, long rounds, int wcpu, int rcpu) {
+    int ls = socket(AF_INET, SOCK_STREAM, 0); if (ls < 0) die("socket");
+    struct sockaddr_in sa; memset(&sa, 0, sizeof(sa));
+    sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+    if (bind(ls, (struct sockaddr *)&sa, sizeof(sa)) < 0) die("bind");
+    socklen_t sl = sizeof(sa); getsockname(ls, (struct sockaddr *)&sa, &sl);
+    listen(ls, 16);
+    int *wfd = calloc((size_t)k, sizeof(int));
+    struct fan_arg fa; fa.epfd = epoll_create1(0); atomic_init(&fa.stop, 0); atomic_init(&fa.rx, 0);
+    for (int i = 0; i < k; i++) {
+        int cfd = socket(AF_INET, SOCK_STREAM, 0);
+        if (connect(cfd, (struct sockaddr *)&sa, sizeof(sa)) < 0) die("connect");
+        wfd[i] = accept(ls, NULL, NULL); if (wfd[i] < 0) die("accept");
+        struct epoll_event ev; ev.events = EPOLLIN; ev.data.fd = cfd;
+        epoll_ctl(fa.epfd, EPOLL_CTL_ADD, cfd, &ev);
+    }
+    pthread_t rt; pthread_create(&rt, NULL, fan_reader, &fa);
+    cpu_set_t set;
+    if (rcpu >= 0) { CPU_ZERO(&set); CPU_SET(rcpu, &set); pthread_setaffinity_np(rt, sizeof(set), &set); }
+    if (wcpu >= 0) { CPU_ZERO(&set); CPU_SET(wcpu, &set); pthread_setaffinity_np(pthread_self(), sizeof(set), &set); }
+    char *buf = malloc((size_t)bytes); memset(buf, 'x', (size_t)bytes); buf[bytes - 1] = '\n';
+    /* closed loop like the talker's single sender: a round of K writes, then wait until the
+       readers hold every byte, so each write is a full transmit + loopback receive + ACK */
+    unsigned long long want = 0; double cpu_ns = 0;
+    struct timespec c0, c1; uint64_t t0 = 0;
+    for (long r = -20; r < rounds; r++) {
+        if (r == 0) { t0 = now_ns(); cpu_ns = 0; }
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
+        for (int i = 0; i < k; i++) if (write(wfd[i], buf, (size_t)bytes) < 0) die("write");
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c1);
+        cpu_ns += (double)(c1.tv_sec - c0.tv_sec) * 1e9 + (double)(c1.tv_nsec - c0.tv_nsec);
+        want += (unsigned long long)bytes * (unsigned long long)k;
+        while (atomic_load(&fa.rx) < want) {}
+    }
+    uint64_t t1 = now_ns();
+    double n = (double)rounds * (double)k;
+    printf("{\"probe\":\"fanout\",\"bytes\":%d,\"sockets\":%d,\"rounds\":%ld,\"wall_ns_per_write\":%.1f,\"cpu_ns_per_write\":%.1f,\"writes_per_s\":%.0f}\n",
+           bytes, k, rounds, (double)(t1 - t0) / n, cpu_ns / n, n / ((double)(t1 - t0) / 1e9));
+    atomic_store(&fa.stop, 1); pthread_join(rt, NULL);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ main */
 int main(int argc, char **argv) {
     signal(SIGPIPE, SIG_IGN);
     if (argc >= 4 && !strcmp(argv[1], "--probe-write")) return probe_write(atoi(argv[2]), atol(argv[3]));
+    if (argc >= 5 && !strcmp(argv[1], "--probe-fanout"))
+        return probe_fanout(atoi(argv[2]), atoi(argv[3]), atol(argv[4]), argc > 5 ? atoi(argv[5]) : -1, argc > 6 ? atoi(argv[6]) : -1);
     FILE *fp = stdin;
     if (argc >= 2) { fp = fopen(argv[1], "r"); if (!fp) die("open spec"); }
     parse_spec(fp);

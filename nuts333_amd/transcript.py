@@ -1,0 +1,256 @@
+"""Deterministic scripted telnet clients: capture byte-exact wire transcripts from a talker.
+
+A *scenario* is a list of steps executed strictly one at a time (the talker drops
+pipelined input, ``nuts333.c:136,149,403-411``).  After every step each connected,
+logged-in client performs a ``.version`` round trip (``nuts333.c:3870-3872``): TCP keeps
+per-socket order and the talker is single-threaded, so once a client has seen the version
+reply it has also seen every byte the step caused to be written to it.  The reply itself
+is cut off the capture.  No "quiet for N ms" heuristics -- with one exception: multi-segment
+``raw`` steps pause between segments so the talker read()s each one on its own.
+
+Only two things in a transcript are not a pure function of (accounts, script):
+the peer ``(site:port)`` shown to WIZ+ on sign-on (``nuts333.c:1732``) and the wall clock
+in the prompt (``nuts333.c:2191-2195``); :func:`normalise` masks exactly those.
+"""
+from __future__ import annotations
+
+import re
+import select
+import socket
+import time
+from dataclasses import dataclass, field
+from typing import Iterable
+
+VERSION_LINE = b"NUTS version 3.3.3"
+RESET = b"\x1b[0m"
+
+_SITE_PORT = re.compile(rb"\([A-Za-z0-9_.\-]+:\d{1,5}\)")
+_PROMPT = re.compile(rb"<\d\d:\d\d, \d\d:\d\d, ")
+
+
+def normalise(b: bytes) -> bytes:
+    b = _SITE_PORT.sub(b"(SITE:PORT)", b)
+    return _PROMPT.sub(b"<HH:MM, HH:MM, ", b)
+
+
+def sync_reply(colour: bool, prompt_suffix: bytes = b"") -> bytes:
+    """Exactly what ``.version`` makes write_user emit (``nuts333.c:1315-1365``)."""
+    if colour:
+        return VERSION_LINE + RESET + b"\n\r" + RESET + prompt_suffix
+    return VERSION_LINE + b"\n\r" + prompt_suffix
+
+
+class ScriptError(RuntimeError):
+    pass
+
+
+@dataclass
+class Client:
+    key: str
+    sock: socket.socket
+    colour: bool = False
+    logged_in: bool = False
+    can_sync: bool = True          # False while in a state where .version is not interpreted
+    sync_suffix: bytes = b""       # bytes a prompt adds after every command reply (command mode)
+    prompt_re: bytes = b""         # regex source for a clock-bearing prompt (prompt on, speech mode)
+    buf: bytearray = field(default_factory=bytearray)
+
+    def read_until(self, suffix_or_pred, timeout: float = 10.0) -> bytes:
+        """Read until the accumulated buffer satisfies the predicate / ends with the suffix."""
+        pred = suffix_or_pred if callable(suffix_or_pred) else (lambda b: b.endswith(suffix_or_pred))
+        deadline = time.monotonic() + timeout
+        while not pred(bytes(self.buf)):
+            left = deadline - time.monotonic()
+            if left <= 0:
+                raise ScriptError(f"client {self.key}: timed out; have {bytes(self.buf)!r}")
+            r, _, _ = select.select([self.sock], [], [], left)
+            if r:
+                d = self.sock.recv(65536)
+                if not d:
+                    raise ScriptError(f"client {self.key}: server closed; have {bytes(self.buf)!r}")
+                self.buf += d
+        out = bytes(self.buf)
+        self.buf.clear()
+        return out
+
+    def send_raw(self, data: bytes) -> None:
+        self.sock.sendall(data)
+
+
+class Session:
+    """Drive several clients against one (or two) talkers and record what each receives."""
+
+    def __init__(self, default_port: int, host: str = "127.0.0.1"):
+        self.host, self.default_port = host, default_port
+        self.clients: dict[str, Client] = {}
+        self.steps: list[dict] = []
+
+    # -- plumbing ----------------------------------------------------------------------
+    def _record(self, what: dict, recv: dict[str, bytes]) -> None:
+        self.steps.append({**what, "recv": {k: normalise(v).decode("latin-1") for k, v in recv.items() if v}})
+
+    def _sync(self, c: Client) -> bytes:
+        """Round trip; returns everything the client had received before the version reply."""
+        reply = sync_reply(c.colour, c.sync_suffix)
+        c.send_raw(b".version\n")
+        if c.prompt_re:
+            pat = re.compile(re.escape(sync_reply(c.colour)) + c.prompt_re + rb"\Z", re.S)
+            got = c.read_until(lambda b: pat.search(b) is not None)
+            return got[: pat.search(got).start()]
+        got = c.read_until(reply)
+        return got[: -len(reply)]
+
+    def _collect(self, actor: Client | None, first: bytes = b"") -> dict[str, bytes]:
+        recv: dict[str, bytes] = {}
+        order = ([actor] if actor else []) + [c for c in self.clients.values() if c is not actor]
+        for c in order:
+            pre = first if c is actor else b""
+            if c.logged_in and c.can_sync:
+                recv[c.key] = pre + self._sync(c)
+            else:
+                recv[c.key] = pre + self._drain_nowait(c)
+        return recv
+
+    @staticmethod
+    def _drain_nowait(c: Client) -> bytes:
+        out = bytes(c.buf)
+        c.buf.clear()
+        while True:
+            r, _, _ = select.select([c.sock], [], [], 0)
+            if not r:
+                return out
+            d = c.sock.recv(65536)
+            if not d:
+                return out
+            out += d
+
+    # -- steps -------------------------------------------------------------------------
+    def connect(self, key: str, port: int | None = None) -> None:
+        s = socket.create_connection((self.host, port or self.default_port))
+        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        c = Client(key, s)
+        self.clients[key] = c
+        banner = c.read_until(b"Give me a name: ")
+        self._record({"op": "connect", "actor": key}, {key: banner})
+
+    def login(self, key: str, name: str, password: str = "test", colour: bool = False,
+              sync_suffix: bytes = b"", prompt_re: bytes = b"") -> None:
+        c = self.clients[key]
+        c.send_raw(name.encode() + b"\n")
+        # the account's colour flag is live as soon as the name is accepted (load_user_details,
+        # nuts333.c:1510,1622), so the password prompt and the IAC WILL ECHO that follows it
+        # (echo_off, nuts333.c:1814-1822) are each followed by a reset when colour is on
+        a = c.read_until(b"\xff\xfb\x01" + (RESET if colour else b""))
+        c.send_raw(password.encode() + b"\n")
+        # login ends with look()'s topic line and, in command mode, the COM> prompt
+        c.colour = colour
+        c.sync_suffix = sync_suffix
+        c.prompt_re = prompt_re
+        tail = (b"has been set yet." + (RESET if colour else b"") + b"\n\r" + (RESET if colour else b""))
+        if prompt_re:
+            pat = re.compile(re.escape(tail) + prompt_re + rb"\Z", re.S)
+            b = c.read_until(lambda x: pat.search(x) is not None)
+        else:
+            b = c.read_until(tail + sync_suffix)
+        c.logged_in = True
+        recv = self._collect(None)
+        recv[key] = a + b + recv.get(key, b"")
+        self._record({"op": "login", "actor": key, "name": name}, recv)
+
+    def line(self, key: str, text: str, note: str = "", expect: bytes | None = None, **flags) -> None:
+        """Send one input line, then sync everybody.  ``flags`` (see :meth:`set_flags`) describe
+        what the line does to the actor's own output state (``.colour``, ``.mode``, ``.prompt``)
+        and take effect before the sync.  With ``expect`` the actor is not synced (the sync
+        command would overwrite the "." repeat buffer, nuts333.c:166-174): its capture ends at
+        the given suffix instead."""
+        c = self.clients[key]
+        c.send_raw(text.encode("latin-1") + b"\n")
+        if flags:
+            self.set_flags(key, **flags)
+        if expect is not None:
+            mine = c.read_until(expect)
+            was, c.can_sync = c.can_sync, False
+            try:
+                recv = self._collect(None)
+            finally:
+                c.can_sync = was
+            recv[key] = mine + recv.get(key, b"")
+            self._record({"op": "line", "actor": key, "send": text, **({"note": note} if note else {})}, recv)
+            return
+        # wait for the first byte of the actor's own output before syncing: the .version line
+        # must not share a read() with this one
+        first = c.read_until(lambda b: len(b) > 0)
+        recv = self._collect(c, first)
+        what = {"op": "line", "actor": key, "send": text}
+        if note:
+            what["note"] = note
+        self._record(what, recv)
+
+    def raw(self, key: str, chunks: Iterable[bytes], note: str = "", expect_output: bool = True) -> None:
+        """Send raw byte chunks (one TCP segment each, in order) -- for input-framing cases."""
+        c = self.clients[key]
+        chunks = list(chunks)
+        first = b""
+        for i, ch in enumerate(chunks):
+            c.send_raw(ch)
+            if i + 1 < len(chunks):
+                # let the talker consume this segment on its own before the next is sent
+                self._settle(c)
+        if expect_output:
+            first = c.read_until(lambda b: len(b) > 0)
+        recv = self._collect(c, first)
+        self._record({"op": "raw", "actor": key, "send": [ch.decode("latin-1") for ch in chunks], "note": note}, recv)
+
+    def _settle(self, c: Client, quiet: float = 0.05) -> None:
+        """Wait until the talker has read the bytes we just sent (its socket receive queue is
+        empty), without sending anything ourselves.  Uses SIOCOUTQ on our side: unacked+unsent
+        bytes drop to zero once the peer's stack has them; then give select() one tick."""
+        import fcntl, struct, termios
+        deadline = time.monotonic() + 2.0
+        while time.monotonic() < deadline:
+            outq = struct.unpack("i", fcntl.ioctl(c.sock.fileno(), termios.TIOCOUTQ, b"\0\0\0\0"))[0]
+            if outq == 0:
+                break
+            time.sleep(0.001)
+        time.sleep(quiet)
+
+    def set_flags(self, key: str, *, colour: bool | None = None, can_sync: bool | None = None,
+                  sync_suffix: bytes | None = None, prompt_re: bytes | None = None) -> None:
+        c = self.clients[key]
+        if colour is not None:
+            c.colour = colour
+        if can_sync is not None:
+            c.can_sync = can_sync
+        if sync_suffix is not None:
+            c.sync_suffix = sync_suffix
+        if prompt_re is not None:
+            c.prompt_re = prompt_re
+
+    def close(self, key: str) -> None:
+        """Leave by closing the socket (never .quit); the others see the SIGN OFF broadcast."""
+        c = self.clients.pop(key)
+        others = list(self.clients.values())
+        c.sock.close()
+        # the talker notices on its next select(); sync the others until one sees SIGN OFF
+        deadline = time.monotonic() + 5.0
+        recv: dict[str, bytes] = {k.key: b"" for k in others}
+        while others and time.monotonic() < deadline:
+            got = self._collect(None)
+            for k, v in got.items():
+                recv[k] += v
+            if any(b"SIGN OFF:" in v for v in recv.values()):
+                # one more pass so every listener has it
+                got = self._collect(None)
+                for k, v in got.items():
+                    recv[k] += v
+                break
+            time.sleep(0.01)
+        self._record({"op": "close", "actor": key}, recv)
+
+    def shutdown(self) -> None:
+        for c in list(self.clients.values()):
+            try:
+                c.sock.close()
+            except OSError:
+                pass
+        self.clients.clear()

@@ -100,9 +100,9 @@ class Spec:
         self.expected_deliveries += len(recipients)
 
     def render(self, server_pids: Sequence[int], threads: int, cpus: Sequence[int], timeout_s: float,
-               login_window: int, spin: bool = True) -> str:
+               login_window: int, spin: bool = True, quickack: bool = True) -> str:
         out = [f"threads {threads}", f"login_window {login_window}", f"timeout_s {timeout_s}",
-               f"expect_lines {self.expect_lines}", f"spin {int(spin)}"]
+               f"expect_lines {self.expect_lines}", f"spin {int(spin)}", f"quickack {int(quickack)}"]
         if cpus:
             out.append("cpus " + ",".join(str(c) for c in cpus))
         out += [f"server_pid {p}" for p in server_pids]

@@ -1,0 +1,272 @@
+"""Transcript scenarios: the scripted inputs whose byte-exact outputs pin the hot path.
+
+Shared by ``tests/golden/make_golden.py`` (which runs them against the reference build,
+``oracle/_ref/nuts333``, and writes ``tests/golden/*.json``) and by the parity tests (which
+replay them against ``oracle/_build/talker_port`` and, where it is present, the reference
+again).  Each scenario returns ``(TalkerConfig kwargs, accounts, script)`` where ``script``
+is a callable driving a :class:`nuts333_amd.transcript.Session`.
+
+What they pin, by reference function:
+  speech_*      say / shout / tell + siblings, write_room_except, write_user   c:4062-4300, 1401-1429, 1291-1366
+  markup        the ``~XX`` / ``/~`` transducer in both colour states           c:1315-1362
+  filters       ignall, ignshout, igntell, invisible sender, room scoping       c:1410-1415, 4156-4167, 4096
+  errors        usage / level / muzzle / unknown-user early-outs                c:3782-3784, 4068-4079, 4110-4118, 4135-4148
+  framing       terminate, char-mode assembly, pipelining drop, "." repeat      c:136-175, 369-411
+  review        record / record_tell ring buffers                               c:2062-2082
+  prompt        prompt() in speech and command mode                             c:2174-2197
+"""
+from __future__ import annotations
+
+from nuts333_amd import provision as pv
+
+A, B, C, D = "Alice", "Bobby", "Carol", "Dave"
+
+
+def _acc(name, **kw):
+    return pv.Account(name, **{"desc": f"is {name.lower()}", **kw})
+
+
+def speech_colour_off():
+    accounts = [_acc(A), _acc(B), _acc(C)]
+
+    def script(s):
+        for k, n in (("a", A), ("b", B), ("c", C)):
+            s.connect(k); s.login(k, n)
+        s.line("c", ".go hallway")                    # c leaves the room: say must not reach it, shout must
+        s.line("a", "hello world")
+        s.line("a", "is anybody there?")
+        s.line("a", "watch out!")
+        s.line("b", ".say explicit say command")
+        s.line("a", ".shout hi all")
+        s.line("a", "! shortcut shout")
+        s.line("a", ".tell bobby a private word")
+        s.line("a", "> carol a question for you?")
+        s.line("b", ".tell al partial-name match fails; exact-then-substring lookup")
+        s.line("b", ".tell lic substring of Alice")
+        s.line("a", ";waves")
+        s.line("a", ".emote nods slowly")
+        s.line("a", "#cheers loudly")
+        s.line("a", ".semote grins")
+        s.line("a", "< bobby winks")
+        s.line("a", ".pemote carol bows")
+        s.line("a", "- an echoed line")
+        s.line("a", ".sh abbreviated command name")
+        s.line("a", ".s first match in the table wins")   # 'say' precedes 'shout' (nuts333.h:157-159)
+        s.close("b")
+        s.line("a", "after bobby left")
+
+    return {}, accounts, script
+
+
+def speech_colour_mixed():
+    accounts = [_acc(A, colour=1), _acc(B, colour=0), _acc(C, colour=1)]
+
+    def script(s):
+        s.connect("a"); s.login("a", A, colour=True)
+        s.connect("b"); s.login("b", B)
+        s.connect("c"); s.login("c", C, colour=True)
+        s.line("a", "plain say, colour recipients get resets")
+        s.line("b", ".shout bold prefix for colour users")
+        s.line("b", ".tell alice bold tell")
+        s.line("c", ".tell bobby stripped for bobby")
+        s.line("a", ";emotes")
+        s.line("b", "#semotes")
+        s.line("b", ".colour", colour=True)
+        s.line("a", "now bobby has colour too")
+        s.line("a", ".colour", colour=False)
+        s.line("c", ".shout alice switched it off")
+
+    return {}, accounts, script
+
+
+def markup():
+    accounts = [_acc(A, colour=1), _acc(B, colour=0)]
+
+    def script(s):
+        s.connect("a"); s.login("a", A, colour=True)
+        s.connect("b"); s.login("b", B)
+        codes = "RS OL UL LI RV FK FR FG FY FB FM FT FW BK BR BG BY BB BM BT BW".split()
+        s.line("b", "all codes " + " ".join(f"~{c}{c.lower()}" for c in codes))
+        s.line("b", "unknown ~ZZ code and ~fr lower case")
+        s.line("b", "escaped /~FR stays text, /~ alone, // and / ~")
+        s.line("b", "trailing tilde ~")
+        s.line("b", "one letter after ~F")
+        s.line("b", "adjacent ~FR~BGcodes~RS~RS")
+        s.line("b", "~OLstarts with a code")
+        s.line("b", ".shout ~FYyellow shout~RS done")
+        s.line("b", ".tell alice ~ULunderlined~RS tell /~OL")
+        s.line("a", "~~ double tilde ~~FR and /~~FG")
+        s.line("a", "x" * 40 + " ~FR" + "y" * 40)
+
+    return {}, accounts, script
+
+
+def filters():
+    accounts = [_acc(A), _acc(B), _acc(C), _acc(D, level=3)]
+
+    def script(s):
+        for k, n in (("a", A), ("b", B), ("c", C), ("d", D)):
+            s.connect(k); s.login(k, n)
+        s.line("b", ".ignshout")
+        s.line("a", ".shout bobby should not hear this")
+        s.line("a", "#nor this semote")
+        s.line("a", "but bobby hears a say")
+        s.line("b", ".ignshout")
+        s.line("c", ".ignall")
+        s.line("a", "carol ignores everything")
+        s.line("a", ".shout including shouts")
+        s.line("a", ".tell carol and tells")
+        s.line("d", ".tell carol but an ARCH gets through")
+        s.line("c", ".ignall")
+        s.line("b", ".igntell")
+        s.line("a", ".tell bobby ignored tell")
+        s.line("a", "< bobby ignored pemote")
+        s.line("b", ".igntell")
+        s.line("d", ".invis")
+        s.line("d", "a presence speaks")
+        s.line("d", ".shout a presence shouts")
+        s.line("d", ".tell alice a presence tells")
+        s.line("d", ";a presence emotes")
+        s.line("d", ".vis")
+        s.line("d", "visible again")
+
+    return {}, accounts, script
+
+
+def errors():
+    accounts = [_acc(A), _acc(B, muzzled=2), _acc(C, level=0), _acc(D, command_mode=1)]
+
+    def script(s):
+        s.connect("a"); s.login("a", A)
+        s.connect("b"); s.login("b", B)
+        s.connect("c"); s.login("c", C)
+        s.connect("d"); s.login("d", D, sync_suffix=b"COM> ")
+        s.line("a", ".shout")
+        s.line("a", ".tell")
+        s.line("a", ".tell bobby")
+        s.line("a", ".tell nobody hello there")
+        s.line("a", ".tell alice hello me")
+        s.line("a", ".say")
+        s.line("a", ".bogus command")
+        s.line("a", ". ")
+        s.line("a", ".pemote alice self")
+        s.line("a", ".pemote")
+        s.line("a", ".echo")
+        s.line("a", ";")
+        s.line("a", "#")
+        s.line("b", "muzzled say")
+        s.line("b", ".shout muzzled shout")
+        s.line("b", ".tell alice muzzled tell")
+        s.line("b", ";muzzled emote")
+        s.line("b", "#muzzled semote")
+        s.line("b", "- muzzled echo")
+        s.line("c", "a NEW user may say")
+        s.line("c", ".shout but not shout")
+        s.line("c", ".tell alice nor tell")
+        s.line("d", "say")                            # command mode: bare word is a command -> "Say what?"
+        s.line("d", "say in command mode")
+        s.line("d", "shout from command mode")
+        s.line("d", "hello")                          # unknown command in command mode
+
+    return {}, accounts, script
+
+
+def swearing():
+    accounts = [_acc(A), _acc(B)]
+
+    def script(s):
+        s.connect("a"); s.login("a", A)
+        s.connect("b"); s.login("b", B)
+        s.line("a", "what the FuCk")
+        s.line("a", ".shout oh shit")
+        s.line("a", ";says cunt")
+        s.line("a", "scunthorpe problem")
+        s.line("a", ".tell bobby shit is allowed in tells")
+        s.line("a", "#shit is allowed in semotes")
+        s.line("a", "clean line")
+
+    return {"ban_swearing": True}, accounts, script
+
+
+def framing():
+    accounts = [_acc(A), _acc(B)]
+
+    def script(s):
+        s.connect("a"); s.login("a", A)
+        s.connect("b"); s.login("b", B)
+        s.raw("a", [b"pipeA\npipeB\npipeC\n"], note="pipelined lines in one segment: only the first survives")
+        s.raw("a", [b"crlf line\r\n"], note="telnet CR LF: cut at CR")
+        s.raw("a", [b"tab\there\n"], note="cut at the first control character")
+        s.raw("a", [b"char", b"mode ", b"typing\n"], note="character-mode client: bytes without newline are buffered")
+        s.raw("a", [b"del", b"ete\x7f\x7f\x7fay\n"], note="DEL erases buffered characters")
+        s.raw("a", [b"ab", b"\x08\x08\x08\x08cd\n"], note="backspace below zero is ignored")
+        s.raw("a", [b"\xff\xfd\x01", b"after IAC\n"], note="IAC replies are ignored", expect_output=True)
+        s.line("a", "repeat me", expect=b"You say: repeat me\n\r")
+        s.line("a", ".", expect=b"You say: repeat me\n\r", note="a lone dot re-runs the previous line")
+        s.line("a", ".", expect=b"You say: repeat me\n\r", note="and again: the dot itself is not stored")
+        s.line("a", "   leading spaces kept")
+        s.line("a", "w1 w2 w3 w4 w5 w6 w7 w8 w9 w10 w11 w12")
+        s.line("a", "x" * 300)
+        s.line("a", ".tell " + "b" * 50 + " long first word")
+        s.line("a", ".shout " + "long " * 190)
+        s.line("a", "high bit bytes \xe9\xe8 are cut")
+
+    return {}, accounts, script
+
+
+def review():
+    accounts = [_acc(A), _acc(B)]
+
+    def script(s):
+        s.connect("a"); s.login("a", A)
+        s.connect("b"); s.login("b", B)
+        for i in range(17):
+            s.line("a" if i % 2 == 0 else "b", f"review line {i:02d}")
+        s.line("a", ";emotes into the buffer")
+        s.line("a", "- echoes into the buffer")
+        s.line("a", ".shout shouts are not recorded")
+        s.line("a", ".review")
+        for i in range(7):
+            s.line("a", f".tell bobby tell number {i}")
+        s.line("a", "< bobby pemote is recorded too")
+        s.line("b", ".revtell")
+        s.line("a", ".revtell")
+        s.line("a", "y" * 250)
+        s.line("b", ".review")
+
+    return {}, accounts, script
+
+
+def prompts():
+    accounts = [_acc(A, prompt=1), _acc(B, command_mode=1), _acc(C, prompt=1, colour=1)]
+    pa = rb"<\d\d:\d\d, \d\d:\d\d, Alice>\n\r"
+    pc = rb"\x1b\[36m<\d\d:\d\d, \d\d:\d\d, Carol>\x1b\[0m\n\r\x1b\[0m"
+    pc_invis = rb"\x1b\[36m<\d\d:\d\d, \d\d:\d\d, Carol\+>\x1b\[0m\n\r\x1b\[0m"
+
+    def script(s):
+        s.connect("a"); s.login("a", A, prompt_re=pa)
+        s.connect("b"); s.login("b", B, sync_suffix=b"COM> ")
+        s.connect("c"); s.login("c", C, colour=True, prompt_re=pc)
+        s.line("a", "a prompt follows every line")
+        s.line("b", "say hello from command mode")
+        s.line("b", "shout and a shout")
+        s.line("c", ".tell alice prompts on both ends")
+        s.line("b", "mode", sync_suffix=b"")
+        s.line("b", "back in speech mode")
+        s.line("a", ".prompt", prompt_re=b"")
+        s.line("a", "no prompt now")
+
+    return {}, accounts, script
+
+
+SCENARIOS = {
+    "speech_colour_off": speech_colour_off,
+    "speech_colour_mixed": speech_colour_mixed,
+    "markup": markup,
+    "filters": filters,
+    "errors": errors,
+    "swearing": swearing,
+    "framing": framing,
+    "review": review,
+    "prompts": prompts,
+}
