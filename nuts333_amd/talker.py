@@ -138,6 +138,16 @@ class Talker:
     def __exit__(self, *exc) -> None:
         self.stop()
 
+    def wait_syslog(self, needle: str, timeout: float = 10.0) -> None:
+        """Block until ./syslog contains ``needle`` (e.g. the netlink 'verified' line, nuts333.c:3428)."""
+        deadline = time.monotonic() + timeout
+        path = self.root / "syslog"
+        while time.monotonic() < deadline:
+            if path.exists() and needle in path.read_text(errors="replace"):
+                return
+            time.sleep(0.02)
+        raise TimeoutError(f"{needle!r} never appeared in {path}")
+
     # -- /proc sampling --------------------------------------------------------------
     def cpu_times(self) -> tuple[float, float]:
         """(user_s, sys_s) of the daemon from /proc/<pid>/stat fields 14/15."""

@@ -80,8 +80,9 @@ class Client:
 class Session:
     """Drive several clients against one (or two) talkers and record what each receives."""
 
-    def __init__(self, default_port: int, host: str = "127.0.0.1"):
+    def __init__(self, default_port: int, host: str = "127.0.0.1", talker_ports: list[int] | None = None):
         self.host, self.default_port = host, default_port
+        self.talker_ports = talker_ports or [default_port]
         self.clients: dict[str, Client] = {}
         self.steps: list[dict] = []
 
@@ -125,8 +126,8 @@ class Session:
             out += d
 
     # -- steps -------------------------------------------------------------------------
-    def connect(self, key: str, port: int | None = None) -> None:
-        s = socket.create_connection((self.host, port or self.default_port))
+    def connect(self, key: str, talker: int = 0) -> None:
+        s = socket.create_connection((self.host, self.talker_ports[talker]))
         s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
         c = Client(key, s)
         self.clients[key] = c

@@ -290,6 +290,7 @@ def config5(lines: int = 1000, locals_each: int = 10, travellers: int = 5, *, bi
                                sites=[pv.Site("talker2", "127.0.0.1", p2[2], "fred123x")])
         t2 = _boot(tmp / "t2", cfg2, [pv.Account(n) for n in names2], binary, _server_cpu(pin, 0))
         t1 = _boot(tmp / "t1", cfg1, [pv.Account(n) for n in names1], binary, _server_cpu(pin, 1))
+        t1.wait_syslog("Connection to talker2 verified")
         spec = Spec()
         ids1 = [spec.add_client(n, p1[0]) for n in names1]
         ids2 = [spec.add_client(n, p2[0]) for n in names2]

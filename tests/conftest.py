@@ -1,0 +1,40 @@
+"""pytest configuration: markers, import paths, and one-time build of the test infrastructure."""
+from __future__ import annotations
+
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box only)")
+    config.addinivalue_line("markers", "reference: needs oracle/_ref/nuts333 (built where /root/reference exists)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built():
+    """Compile the restatement and the load generator (seconds; gcc only)."""
+    subprocess.run(["make", "-s", "-C", str(REPO / "oracle"), "port"], check=True)
+    from nuts333_amd import workloads
+    workloads.build_loadgen()
+
+
+@pytest.fixture(scope="session")
+def port_binary(built):
+    from nuts333_amd.talker import PORT_BINARY
+    assert PORT_BINARY.exists()
+    return PORT_BINARY
+
+
+@pytest.fixture(scope="session")
+def ref_binary():
+    from nuts333_amd.talker import REF_BINARY
+    if not REF_BINARY.exists():
+        pytest.skip("oracle/_ref/nuts333 not built (no /root/reference on this machine)")
+    return REF_BINARY

@@ -15,41 +15,15 @@ from __future__ import annotations
 
 import json
 import sys
-import tempfile
-from dataclasses import asdict
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(REPO))
 sys.path.insert(0, str(REPO / "tests"))
 
-from nuts333_amd import provision as pv          # noqa: E402
-from nuts333_amd.talker import REF_BINARY, REF_BINARY_O0, Talker, free_ports  # noqa: E402
-from nuts333_amd.transcript import Session       # noqa: E402
-import scenarios                                  # noqa: E402
-
-
-def run_scenario(name: str, binary: Path) -> dict:
-    cfg_kw, accounts, script = scenarios.SCENARIOS[name]()
-    with tempfile.TemporaryDirectory(prefix=f"golden_{name}_") as tmp:
-        ports = free_ports(3)
-        cfg = pv.TalkerConfig(mainport=ports[0], wizport=ports[1], linkport=ports[2], max_users=50, **cfg_kw)
-        pv.write_tree(tmp, cfg, accounts)
-        with Talker(binary, tmp) as talker:
-            sess = Session(ports[0])
-            try:
-                script(sess)
-            finally:
-                sess.shutdown()
-            alive = talker.alive()
-    if not alive:
-        raise RuntimeError(f"talker died during scenario {name}")
-    return {
-        "scenario": name,
-        "config": cfg_kw,
-        "accounts": [asdict(a) for a in accounts],
-        "steps": sess.steps,
-    }
+from nuts333_amd.talker import REF_BINARY, REF_BINARY_O0  # noqa: E402
+import scenarios                                            # noqa: E402
+from scenario_runner import run_scenario                    # noqa: E402
 
 
 def main(argv: list[str]) -> int:

@@ -1,0 +1,62 @@
+"""Run one transcript scenario (tests/scenarios.py) against given talker binaries.
+
+Shared by tests/golden/make_golden.py (reference build -> fixtures) and the parity tests
+(restatement, and the reference again where it is present).  A scenario is either
+single-talker -- ``(config kwargs, accounts, script)`` -- or a dict describing several
+talkers joined by netlinks; in that case ``binaries`` may name a different binary per
+talker, which is how the restatement is tested against the real reference across the wire.
+"""
+from __future__ import annotations
+
+import tempfile
+from dataclasses import asdict
+from pathlib import Path
+from typing import Sequence
+
+from nuts333_amd import provision as pv
+from nuts333_amd.talker import Talker, free_ports
+from nuts333_amd.transcript import Session
+
+import scenarios
+
+
+def run_scenario(name: str, binaries: Path | Sequence[Path]) -> dict:
+    spec = scenarios.SCENARIOS[name]()
+    if isinstance(spec, tuple):
+        cfg_kw, accounts, script = spec
+        spec = {
+            "configs": lambda p: [pv.TalkerConfig(mainport=p[0][0], wizport=p[0][1], linkport=p[0][2], max_users=50, **cfg_kw)],
+            "accounts": [accounts], "boot_order": [0], "script": script, "config_kw": cfg_kw,
+        }
+    n = len(spec["accounts"])
+    if isinstance(binaries, (str, Path)):
+        binaries = [Path(binaries)] * n
+    assert len(binaries) == n, f"scenario {name} needs {n} binaries"
+    talkers: list[Talker | None] = [None] * n
+    with tempfile.TemporaryDirectory(prefix=f"scn_{name}_") as tmp:
+        ports = [free_ports(3) for _ in range(n)]
+        cfgs = spec["configs"](ports)
+        sess = Session(ports[0][0], talker_ports=[p[0] for p in ports])
+        try:
+            for i in spec["boot_order"]:
+                root = Path(tmp) / f"t{i}"
+                pv.write_tree(root, cfgs[i], spec["accounts"][i])
+                talkers[i] = Talker(binaries[i], root)
+                talkers[i].start()
+            for i, needle in spec.get("wait_syslog", []):
+                talkers[i].wait_syslog(needle)
+            spec["script"](sess)
+            alive = [t.alive() for t in talkers]
+        finally:
+            sess.shutdown()
+            for t in talkers:
+                if t is not None:
+                    t.stop()
+    if not all(alive):
+        raise RuntimeError(f"a talker died during scenario {name}: alive={alive}")
+    return {
+        "scenario": name,
+        "config": spec.get("config_kw", {}),
+        "accounts": [[asdict(a) for a in accs] for accs in spec["accounts"]],
+        "steps": sess.steps,
+    }

@@ -14,6 +14,8 @@ What they pin, by reference function:
   framing       terminate, char-mode assembly, pipelining drop, "." repeat      c:136-175, 369-411
   review        record / record_tell ring buffers                               c:2062-2082
   prompt        prompt() in speech and command mode                             c:2174-2197
+  netlink       two talkers: TRANS/GRANTED, ACT relay, MSG..EMSG frames, PRM,   c:2946-3073, 3077-3285, 1299-1306,
+                REMVD on the way home, offsite tell, home execution               3452-3479, 3787-3806, 4168-4172
 """
 from __future__ import annotations
 
@@ -259,6 +261,57 @@ def prompts():
     return {}, accounts, script
 
 
+def netlink():
+    """talker 0 ("talker1") dials talker 1 ("talker2") at boot; Alice travels there and back."""
+    acc1 = [_acc(A), _acc(D)]
+    acc2 = [_acc(B), _acc(C, colour=1)]
+
+    def configs(p):
+        rooms1 = tuple(pv.Room(r.label, r.name, r.links, r.access, "CONNECT talker2" if r.name == "drive" else "",
+                               r.description) for r in pv.DEFAULT_ROOMS)
+        cfg1 = pv.TalkerConfig(mainport=p[0][0], wizport=p[0][1], linkport=p[0][2], max_users=50, verification="verify1",
+                               auto_connect=True, rooms=rooms1, sites=[pv.Site("talker2", "127.0.0.1", p[1][2], "verify2")])
+        # the accepting side matches the dialler by its reverse-resolved site string
+        # (nuts333.c:322, 2908-2909): list both spellings
+        cfg2 = pv.TalkerConfig(mainport=p[1][0], wizport=p[1][1], linkport=p[1][2], max_users=50, verification="verify2",
+                               sites=[pv.Site("talker1", "localhost", p[0][2], "verify1"),
+                                      pv.Site("talker1", "127.0.0.1", p[0][2], "verify1")])
+        return [cfg1, cfg2]
+
+    look_end = b"has been set yet.\n\r"
+
+    def script(s):
+        s.connect("a", talker=0); s.login("a", A)
+        s.connect("d", talker=0); s.login("d", D)
+        s.connect("b", talker=1); s.login("b", B)
+        s.connect("c", talker=1); s.login("c", C, colour=True)
+        for hop in pv.WALKS["lounge"]:                 # the ACCEPT room of talker2 is its lounge
+            s.line("b", f".go {hop}")
+            s.line("c", f".go {hop}")
+        s.line("a", "said on talker1 before leaving")
+        s.line("a", ".go talker2", expect=look_end, note="TRANS -> GRANTED -> ACT look -> MSG frames")
+        s.line("a", "hello from afar")
+        s.line("a", "a question from afar?")
+        s.line("a", ".shout shouting on talker2")
+        s.line("b", ".shout bobby shouts back")
+        s.line("b", ".tell alice a tell across the link")
+        s.line("a", ".tell bobby and an answer?")
+        s.line("a", ";waves from afar")
+        s.line("c", "~FRcoloured~RS say reaches alice stripped at home")
+        s.line("d", ".tell alice are you there")
+        s.line("d", ".shout heard on talker1 only")
+        s.line("a", ".look")
+        s.line("a", ".colour", colour=True, note="home execution")
+        s.line("c", "~FRcoloured~RS say reaches alice in colour now")
+        s.line("a", ".colour", colour=False)
+        s.line("a", ".go talker1", expect=look_end, note="REMVD: back home")
+        s.line("a", "home again")
+        s.line("b", ".shout alice no longer hears talker2")
+
+    return {"configs": configs, "accounts": [acc1, acc2], "boot_order": [1, 0],
+            "wait_syslog": [(0, "Connection to talker2 verified")], "script": script}
+
+
 SCENARIOS = {
     "speech_colour_off": speech_colour_off,
     "speech_colour_mixed": speech_colour_mixed,
@@ -269,4 +322,5 @@ SCENARIOS = {
     "framing": framing,
     "review": review,
     "prompts": prompts,
+    "netlink": netlink,
 }

@@ -1,0 +1,75 @@
+"""Parity: the restated path reproduces, byte for byte, what the reference put on the wire.
+
+tests/golden/*.json were captured from the unmodified reference build by
+tests/golden/make_golden.py.  Here the same scripted clients are replayed against
+oracle/_build/talker_port; every byte every client receives at every step must match.
+Where the reference build is present (this container, not the GPU box) it is replayed too,
+which keeps the fixtures honest; and the netlink scenario is additionally run with one side
+the restatement and the other the real reference, in both orders -- the strongest
+conformance check of the wire protocol available.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import pytest
+
+import scenarios
+from scenario_runner import run_scenario
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+NAMES = list(scenarios.SCENARIOS)
+
+
+def _load(name):
+    return json.loads((GOLDEN / f"{name}.json").read_text())
+
+
+def _diff(gold, got):
+    for i, (a, b) in enumerate(zip(gold, got)):
+        if a != b:
+            lines = [f"first difference at step {i}: op={a.get('op')} actor={a.get('actor')} send={a.get('send')!r}"]
+            for k in sorted(set(a["recv"]) | set(b["recv"])):
+                if a["recv"].get(k) != b["recv"].get(k):
+                    lines += [f"  client {k} golden: {a['recv'].get(k)!r}", f"  client {k} got   : {b['recv'].get(k)!r}"]
+            return "\n".join(lines)
+    return f"step count differs: golden {len(gold)} got {len(got)}"
+
+
+def test_every_scenario_has_a_fixture():
+    assert sorted(p.stem for p in GOLDEN.glob("*.json")) == sorted(NAMES)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_port_matches_golden(name, port_binary):
+    gold = _load(name)["steps"]
+    got = run_scenario(name, port_binary)["steps"]
+    assert got == gold, _diff(gold, got)
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("name", NAMES)
+def test_reference_still_matches_golden(name, ref_binary):
+    gold = _load(name)["steps"]
+    got = run_scenario(name, ref_binary)["steps"]
+    assert got == gold, _diff(gold, got)
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("order", ["port_dials_reference", "reference_dials_port"])
+def test_netlink_interop_with_reference(order, port_binary, ref_binary):
+    """talker 0 dials talker 1; mix the implementations across the link."""
+    bins = [port_binary, ref_binary] if order == "port_dials_reference" else [ref_binary, port_binary]
+    gold = _load("netlink")["steps"]
+    got = run_scenario("netlink", bins)["steps"]
+    assert got == gold, _diff(gold, got)
+
+
+def test_fixtures_contain_no_reference_source():
+    """A fixture is data: provisioning, inputs, received bytes -- nothing else."""
+    for p in GOLDEN.glob("*.json"):
+        d = json.loads(p.read_text())
+        assert set(d) == {"scenario", "config", "accounts", "steps"}
+        for st in d["steps"]:
+            assert set(st) <= {"op", "actor", "name", "send", "note", "recv"}
