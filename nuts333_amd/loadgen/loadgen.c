@@ -48,7 +48,7 @@
 #define LBUF 4096
 #define RBUF 65536
 
-static const char LOOK_END_1[] = "has been set yet.\n\r";   /* nuts333.c:4003 */
+static const char LOOK_END_1[] = "has been set yet.*\n\r"; /* nuts333.c:4003; '*' = any bytes (ESC[0m with colour on) */
 static const char NAME_PROMPT[] = "Give me a name: ";       /* nuts333.c:309  */
 static const char PASS_PROMPT[] = "Give me a password: ";   /* nuts333.c:1536 */
 
@@ -64,7 +64,7 @@ struct client {
     /* phase buffer for prompt matching (login / placement) */
     char *acc; size_t acc_len, acc_cap;
     struct precmd *pre; int npre, ipre, cap_pre;
-    char **lines; int *linelen; int nlines, iline, cap_lines;
+    struct sched { char **lines; int *len; int n, i, cap; } warm, timed, *cur;
     int awaiting_ack;
     uint64_t sent_ns;
     char lbuf[LBUF]; int llen;
@@ -84,9 +84,10 @@ static struct worker g_workers[MAX_THREADS]; static int g_nthreads = 4;
 static int g_login_window = 4;
 static double g_timeout_s = 300.0;
 static int g_server_pids[MAX_SERVERS], g_nservers;
-static uint64_t g_expect_lines;
+static uint64_t g_expect_lines, g_expect_warm;
 static int g_cpus[256], g_ncpus;
 static int g_verbose;
+static int g_quiet_ms = 40;   /* drain until every socket of the worker has been silent this long */
 static int g_quickack = 1; /* re-arm TCP_QUICKACK after every read: the talker never sets TCP_NODELAY, so a second
                               small write to the same socket waits (Nagle) for our ACK, which the kernel would
                               otherwise delay by up to 40 ms -- that would time the delayed-ACK timer, not the talker */
@@ -130,9 +131,11 @@ static void parse_spec(FILE *fp) {
         else if (!strncmp(line, "login_window ", 13)) g_login_window = atoi(line + 13);
         else if (!strncmp(line, "timeout_s ", 10)) g_timeout_s = atof(line + 10);
         else if (!strncmp(line, "verbose ", 8)) g_verbose = atoi(line + 8);
+        else if (!strncmp(line, "drain_quiet_ms ", 15)) g_quiet_ms = atoi(line + 15);
         else if (!strncmp(line, "spin ", 5)) g_spin = atoi(line + 5);
         else if (!strncmp(line, "quickack ", 9)) g_quickack = atoi(line + 9);
         else if (!strncmp(line, "expect_lines ", 13)) g_expect_lines = strtoull(line + 13, NULL, 10);
+        else if (!strncmp(line, "expect_warm_lines ", 18)) g_expect_warm = strtoull(line + 18, NULL, 10);
         else if (!strncmp(line, "server_pid ", 11)) {
             if (g_nservers < MAX_SERVERS) g_server_pids[g_nservers++] = atoi(line + 11);
         } else if (!strncmp(line, "cpus ", 5)) {
@@ -173,18 +176,21 @@ static void parse_spec(FILE *fp) {
             c->pre[c->npre].expect = e;
             c->pre[c->npre].line = strdup(tab + 1);
             c->npre++;
-        } else if (!strncmp(line, "line ", 5)) {
+        } else if (!strncmp(line, "line ", 5) || !strncmp(line, "warm ", 5)) {
+            /* line <idx> <text>: timed phase;  warm <idx> <text>: untimed warm-up phase before it */
+            int is_warm = line[0] == 'w';
             char *p = line + 5; int idx = (int)strtol(p, &p, 10);
             if (*p == ' ') p++;
             struct client *c = client_at(idx);
-            if (c->nlines == c->cap_lines) {
-                c->cap_lines = c->cap_lines ? c->cap_lines * 2 : 16;
-                c->lines = realloc(c->lines, sizeof(char *) * (size_t)c->cap_lines);
-                c->linelen = realloc(c->linelen, sizeof(int) * (size_t)c->cap_lines);
+            struct sched *sc = is_warm ? &c->warm : &c->timed;
+            if (sc->n == sc->cap) {
+                sc->cap = sc->cap ? sc->cap * 2 : 16;
+                sc->lines = realloc(sc->lines, sizeof(char *) * (size_t)sc->cap);
+                sc->len = realloc(sc->len, sizeof(int) * (size_t)sc->cap);
             }
             size_t l = strlen(p);
-            char *s = malloc(l + 2); memcpy(s, p, l); s[l] = '\n'; s[l + 1] = 0;
-            c->lines[c->nlines] = s; c->linelen[c->nlines] = (int)l + 1; c->nlines++;
+            char *t = malloc(l + 2); memcpy(t, p, l); t[l] = '\n'; t[l + 1] = 0;
+            sc->lines[sc->n] = t; sc->len[sc->n] = (int)l + 1; sc->n++;
         } else { fprintf(stderr, "spec: unknown directive: %s\n", line); exit(2); }
     }
     free(line);
@@ -223,8 +229,15 @@ static void acc_add(struct client *c, const char *b, size_t n) {
     }
     memcpy(c->acc + c->acc_len, b, n); c->acc_len += n; c->acc[c->acc_len] = 0;
 }
+/* needle may contain one '*': the part before it must occur, and the part after it later on */
 static int acc_has(struct client *c, const char *needle) {
-    return c->acc_len && memmem(c->acc, c->acc_len, needle, strlen(needle)) != NULL;
+    if (!c->acc_len) return 0;
+    const char *star = strchr(needle, '*');
+    if (!star) return memmem(c->acc, c->acc_len, needle, strlen(needle)) != NULL;
+    const char *a = memmem(c->acc, c->acc_len, needle, (size_t)(star - needle));
+    if (!a) return 0;
+    a += star - needle;
+    return memmem(a, c->acc_len - (size_t)(a - c->acc), star + 1, strlen(star + 1)) != NULL;
 }
 
 static void start_connect(struct worker *w, struct client *c) {
@@ -305,11 +318,12 @@ static inline int is_ack_line(const char *s, int len) {
 }
 
 static void send_next(struct client *c) {
-    if (c->iline < c->nlines) {
+    struct sched *sc = c->cur;
+    if (sc && sc->i < sc->n) {
         c->awaiting_ack = 1;
         c->sent_ns = now_ns();
-        send_all(c, c->lines[c->iline], c->linelen[c->iline]);
-        c->iline++;
+        send_all(c, sc->lines[sc->i], sc->len[sc->i]);
+        sc->i++;
     }
 }
 
@@ -372,6 +386,19 @@ static int drain_client(struct worker *w, struct client *c, char *rbuf, int runn
     return total;
 }
 
+/* Everything the logins / placement / warm-up caused is already written by the talker (it writes
+   the acting user's own output last), but may still be in flight -- over a netlink it can sit
+   behind Nagle + a delayed ACK for tens of ms.  Read until all our sockets stay silent. */
+static void drain_until_quiet(struct worker *w, char *rbuf) {
+    uint64_t last = now_ns();
+    while (now_ns() - last < (uint64_t)g_quiet_ms * 1000000ull && !atomic_load(&g_fail)) {
+        int got = 0;
+        for (int i = 0; i < w->ncl; i++) if (drain_client(w, w->cl[i], rbuf, 0) > 0) got = 1;
+        if (got) last = now_ns();
+        usleep(1000);
+    }
+}
+
 static void *worker_main(void *arg) {
     struct worker *w = arg;
     char *rbuf = malloc(RBUF);
@@ -380,7 +407,7 @@ static void *worker_main(void *arg) {
         cpu_set_t set; CPU_ZERO(&set); CPU_SET(w->cpu, &set);
         pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
     }
-    int announced_ready = 0, announced_drained = 0, started_run = 0;
+    int announced_ready = 0, announced_drained = 0, started_run = 0, started_warm = 0;
     uint64_t pub_lines = 0, pub_bytes = 0, pub_acks = 0;
     while (!atomic_load(&g_fail)) {
         int phase = atomic_load(&g_phase);
@@ -392,17 +419,28 @@ static void *worker_main(void *arg) {
                 announced_ready = 1; atomic_fetch_add(&g_ready_workers, 1);
             }
         }
-        if (phase == 1 && !announced_drained) {
-            /* every broadcast caused by logins/placement is already queued on our sockets
-               (the talker writes the acting user's own look() output last); empty them */
-            for (int pass = 0; pass < 2; pass++) {
-                for (int i = 0; i < w->ncl; i++) drain_client(w, w->cl[i], rbuf, 0);
-                usleep(20000);
-            }
+        if (phase == 4 && !started_warm) {
+            /* untimed warm-up: same closed-loop machinery, its own schedule and counters */
+            drain_until_quiet(w, rbuf);
             for (int i = 0; i < w->ncl; i++) {
                 struct client *c = w->cl[i];
-                c->st = ST_RUN; c->llen = 0; c->rx_lines = c->rx_bytes = c->rx_acks = 0;
+                c->st = ST_RUN; c->llen = 0; c->rx_lines = c->rx_bytes = c->rx_acks = 0; c->cur = &c->warm;
             }
+            started_warm = 1; started_run = 1; pub_lines = pub_bytes = pub_acks = 0;
+            for (int i = 0; i < w->ncl; i++) send_next(w->cl[i]);
+            continue;
+        }
+        if (phase == 1 && !announced_drained) {
+            started_run = 0;
+            /* every broadcast caused by logins/placement is already queued on our sockets
+               (the talker writes the acting user's own look() output last); empty them */
+            drain_until_quiet(w, rbuf);
+            for (int i = 0; i < w->ncl; i++) {
+                struct client *c = w->cl[i];
+                c->st = ST_RUN; c->llen = 0; c->rx_lines = c->rx_bytes = c->rx_acks = 0; c->cur = &c->timed;
+                c->awaiting_ack = 0;
+            }
+            pub_lines = pub_bytes = pub_acks = 0; w->nlat = 0;
             announced_drained = 1; atomic_fetch_add(&g_drained_workers, 1);
             pthread_barrier_wait(&g_run_barrier);   /* main records t0 then joins */
             pthread_barrier_wait(&g_run_barrier);
@@ -424,7 +462,7 @@ static void *worker_main(void *arg) {
                 atomic_fetch_add(&g_bytes, b - pub_bytes);
                 atomic_fetch_add(&g_acks, a - pub_acks);
                 pub_lines = l; pub_bytes = b; pub_acks = a;
-                if (tot >= g_expect_lines && !atomic_exchange(&g_done, 1))
+                if (phase == 2 && tot >= g_expect_lines && !atomic_exchange(&g_done, 1))
                     atomic_store(&g_t_end, now_ns());
             }
         }
@@ -591,10 +629,21 @@ int main(int argc, char **argv) {
     uint64_t t_login1 = now_ns();
     struct cpu_sample s0[MAX_SERVERS], s1[MAX_SERVERS];
     uint64_t t0 = 0, t1 = 0; int timed_out = 0;
+    double warm_s = 0.0;
+    if (!atomic_load(&g_fail) && g_expect_warm) {
+        uint64_t w0 = now_ns();
+        atomic_store(&g_phase, 4);
+        while (atomic_load(&g_lines) < g_expect_warm && !atomic_load(&g_fail)) {
+            if (now_ns() > deadline) { fprintf(stderr, "loadgen: warm-up timed out\n"); atomic_store(&g_fail, 1); }
+            usleep(500);
+        }
+        warm_s = (double)(now_ns() - w0) / 1e9;
+    }
     if (!atomic_load(&g_fail)) {
         atomic_store(&g_phase, 1);
         while (atomic_load(&g_drained_workers) < g_nthreads && !atomic_load(&g_fail)) usleep(1000);
         pthread_barrier_wait(&g_run_barrier);
+        atomic_store(&g_lines, 0); atomic_store(&g_bytes, 0); atomic_store(&g_acks, 0);   /* workers are parked */
         for (int i = 0; i < g_nservers; i++) sample_pid(g_server_pids[i], &s0[i]);
         t0 = now_ns();
         atomic_store(&g_phase, 2);
@@ -631,7 +680,7 @@ int main(int argc, char **argv) {
     uint64_t lines = 0, bytes = 0, acks = 0, sent = 0, planned = 0;
     for (int i = 0; i < g_nclients; i++) {
         lines += g_clients[i].rx_lines; bytes += g_clients[i].rx_bytes; acks += g_clients[i].rx_acks;
-        sent += (uint64_t)g_clients[i].iline; planned += (uint64_t)g_clients[i].nlines;
+        sent += (uint64_t)g_clients[i].timed.i; planned += (uint64_t)g_clients[i].timed.n;
     }
     size_t nlat = 0;
     for (int t = 0; t < g_nthreads; t++) nlat += g_workers[t].nlat;
@@ -647,7 +696,7 @@ int main(int argc, char **argv) {
     printf("\"lines_total\":%llu,\"expected_lines\":%llu,\"deliveries\":%llu,\"bytes_total\":%llu,",
            (unsigned long long)lines, (unsigned long long)g_expect_lines,
            (unsigned long long)(lines >= acks ? lines - acks : 0), (unsigned long long)bytes);
-    printf("\"wall_s\":%.6f,\"login_s\":%.3f,", wall, (double)(t_login1 - t_login0) / 1e9);
+    printf("\"wall_s\":%.6f,\"login_s\":%.3f,\"warm_s\":%.3f,", wall, (double)(t_login1 - t_login0) / 1e9, warm_s);
     printf("\"ack_latency_us\":{\"mean\":%.2f,\"p50\":%.2f,\"p99\":%.2f,\"max\":%.2f},",
            lat_mean / 1e3, nlat ? (double)lat[nlat / 2] / 1e3 : 0.0,
            nlat ? (double)lat[(size_t)((double)(nlat - 1) * 0.99)] / 1e3 : 0.0, nlat ? (double)lat[nlat - 1] / 1e3 : 0.0);

@@ -34,7 +34,7 @@ HERE = Path(__file__).resolve().parent
 LOADGEN_SRC = HERE / "loadgen" / "loadgen.c"
 LOADGEN_BIN = HERE / "loadgen" / "loadgen"
 
-LOOK_END = r"has been set yet.\n\r"
+LOOK_END = r"has been set yet.*\n\r"     # '*': any bytes (a colour user gets ESC[0m before the newline)
 
 #: 54-byte payload with a 6-digit sequence number, no '~', no leading command
 #: character, none of the three filtered words (nuts333.h:275-277).
@@ -76,6 +76,8 @@ class Spec:
         self.clients: list[tuple[str, str, str, int]] = []
         self.pre: list[tuple[int, str, str]] = []
         self.lines: list[tuple[int, str]] = []
+        self.warm: list[tuple[int, str]] = []
+        self.expect_warm_lines = 0
         self.expect_lines = 0
         self.expected_deliveries = 0
         self.expected_per_client: list[int] = []
@@ -88,9 +90,14 @@ class Spec:
     def add_pre(self, idx: int, line: str, expect: str = LOOK_END) -> None:
         self.pre.append((idx, expect, line))
 
-    def add_line(self, sender: int, text: str, recipients: Sequence[int]) -> None:
-        """One input line; ``recipients`` are the client indices that must receive one line each."""
+    def add_line(self, sender: int, text: str, recipients: Sequence[int], warm: bool = False) -> None:
+        """One input line; ``recipients`` are the client indices that must receive one line each.
+        ``warm`` lines run in an untimed phase before the timed one."""
         assert "\n" not in text and "\t" not in text and len(text) < 900
+        if warm:
+            self.warm.append((sender, text))
+            self.expect_warm_lines += 1 + len(recipients)
+            return
         self.lines.append((sender, text))
         self.expected_per_client[sender] += 1          # the acknowledgement
         for r in recipients:
@@ -100,14 +107,16 @@ class Spec:
         self.expected_deliveries += len(recipients)
 
     def render(self, server_pids: Sequence[int], threads: int, cpus: Sequence[int], timeout_s: float,
-               login_window: int, spin: bool = True, quickack: bool = True) -> str:
+               login_window: int, spin: bool = True, quickack: bool = True, drain_quiet_ms: int = 40) -> str:
         out = [f"threads {threads}", f"login_window {login_window}", f"timeout_s {timeout_s}",
-               f"expect_lines {self.expect_lines}", f"spin {int(spin)}", f"quickack {int(quickack)}"]
+               f"expect_lines {self.expect_lines}", f"expect_warm_lines {self.expect_warm_lines}",
+               f"spin {int(spin)}", f"quickack {int(quickack)}", f"drain_quiet_ms {drain_quiet_ms}"]
         if cpus:
             out.append("cpus " + ",".join(str(c) for c in cpus))
         out += [f"server_pid {p}" for p in server_pids]
         out += [f"client {n} {p} {h} {port}" for n, p, h, port in self.clients]
         out += [f"pre {i} {e}\t{l}" for i, e, l in self.pre]
+        out += [f"warm {i} {t}" for i, t in self.warm]
         out += [f"line {i} {t}" for i, t in self.lines]
         return "\n".join(out) + "\n"
 
@@ -122,7 +131,9 @@ def run_spec(spec: Spec, talkers: Sequence[Talker], *, timeout_s: float = 600.0,
         threads = max(1, min(len(client_cpus) or len(cpus) - 1 or 1, 14, len(spec.clients)))
     # the talker listens with backlog 10 (nuts333.c:1189): keep concurrent logins below it
     login_window = max(1, 8 // threads)
-    text = spec.render([t.pid for t in talkers], threads, client_cpus, timeout_s, login_window)
+    # talker<->talker traffic sits behind Nagle + delayed ACK (neither side sets TCP_NODELAY): wait longer
+    quiet = 40 if len(talkers) == 1 else 400
+    text = spec.render([t.pid for t in talkers], threads, client_cpus, timeout_s, login_window, drain_quiet_ms=quiet)
     proc = subprocess.run([str(LOADGEN_BIN)], input=text.encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                           timeout=timeout_s + 60)
     try:
@@ -188,22 +199,22 @@ def _run_single(build: Callable[[Spec, int], None], accounts, *, binary: Path, p
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def config1(lines: int = 10_000, *, binary: Path, pin: bool = True, workdir=None, timeout_s: float = 300.0) -> dict:
+def config1(lines: int = 10_000, *, warmup: int = 0, binary: Path, pin: bool = True, workdir=None, timeout_s: float = 300.0) -> dict:
     """1 client, ``.go lounge``, closed-loop say; nobody else hears it (plumbing / latency)."""
     accounts = [pv.Account("Fred", level=4, desc="the GOD account")]
 
     def build(spec: Spec, port: int) -> None:
         c = spec.add_client("Fred", port)
         spec.add_pre(c, ".go lounge")          # GOD teleports (nuts333.c:4399-4404)
-        for i in range(lines):
-            spec.add_line(c, payload(i), [])
+        for i in range(-warmup, lines):
+            spec.add_line(c, payload(i % 1_000_000), [], warm=i < 0)
 
     res = _run_single(build, accounts, binary=binary, pin=pin, workdir=workdir, timeout_s=timeout_s)
     res["workload"] = f"config1: 1 client, {lines} say lines in lounge"
     return res
 
 
-def config2(lines: int = 20_000, n: int = 10, *, colour: int = 0, all_send: bool = False, binary: Path,
+def config2(lines: int = 20_000, n: int = 10, *, colour: int = 0, all_send: bool = False, warmup: int = 0, binary: Path,
             pin: bool = True, workdir=None, timeout_s: float = 300.0) -> dict:
     """n clients in ``drive``; client 0 (or everyone, ``all_send``) says ``lines`` lines."""
     accounts = [pv.Account(pv.bot_name(i), level=1, colour=colour) for i in range(n)]
@@ -212,9 +223,9 @@ def config2(lines: int = 20_000, n: int = 10, *, colour: int = 0, all_send: bool
         ids = [spec.add_client(pv.bot_name(i), port) for i in range(n)]
         senders = ids if all_send else ids[:1]
         per = lines // len(senders)
-        for k in range(per):
+        for k in range(-(warmup // len(senders)), per):
             for s in senders:
-                spec.add_line(s, payload(k), [r for r in ids if r != s])
+                spec.add_line(s, payload(k % 1_000_000), [r for r in ids if r != s], warm=k < 0)
 
     res = _run_single(build, accounts, binary=binary, pin=pin, workdir=workdir, timeout_s=timeout_s, max_users=n + 10)
     res["workload"] = f"config2: {n} clients in one room, {lines} say lines, {'all send' if all_send else 'client 0 sends'}, colour {colour}"
@@ -253,15 +264,15 @@ def config3(per_client: int = 200, n: int = 100, *, seed: int = 333, binary: Pat
     return res
 
 
-def config4(lines: int = 1000, n: int = 1000, *, colour: int = 0, binary: Path, pin: bool = True, workdir=None,
+def config4(lines: int = 1000, n: int = 1000, *, colour: int = 0, warmup: int = 0, binary: Path, pin: bool = True, workdir=None,
             timeout_s: float = 900.0) -> dict:
     """n clients in ``drive``; client 0 ``.shout``s ``lines`` lines (n-1 recipients each)."""
     accounts = [pv.Account(pv.bot_name(i), level=1, colour=colour) for i in range(n)]
 
     def build(spec: Spec, port: int) -> None:
         ids = [spec.add_client(pv.bot_name(i), port) for i in range(n)]
-        for k in range(lines):
-            spec.add_line(ids[0], ".shout " + payload(k), ids[1:])
+        for k in range(-warmup, lines):
+            spec.add_line(ids[0], ".shout " + payload(k % 1_000_000), ids[1:], warm=k < 0)
 
     res = _run_single(build, accounts, binary=binary, pin=pin, workdir=workdir, timeout_s=timeout_s, max_users=n + 10)
     res["workload"] = f"config4: {n} clients, client 0 shouts {lines} lines, colour {colour}"
