@@ -7,6 +7,10 @@ Launch rules, each a measured reference behaviour:
   daemon's PID is taken from the boot line the child appends to ``./syslog``
   (``nuts333.c:86-87``, ``1434-1444``);
 * stdout/stderr go to a file, never a pipe (the daemon keeps the descriptors open);
+* argv[0] is kept short: the reference does ``strcpy(progname,argv[0])`` into a 40-byte
+  global (``nuts333.c:62``, ``nuts333.h:283``), so starting it by a long absolute path
+  overflows -- the -O2 build aborts with "buffer overflow detected" (FORTIFY), the -O0 build
+  silently corrupts ``confile``.  Found on the GPU box, whose checkout path is long;
 * it is stopped with SIGKILL once every client socket is closed: the SIGTERM path runs
   ``talker_shutdown`` which walks freed list nodes (``nuts333.c:4044``).
 """
@@ -74,7 +78,8 @@ class Talker:
                     pass
 
         try:
-            launcher = subprocess.Popen([str(self.binary), self.config_name], cwd=self.root, stdin=subprocess.DEVNULL,
+            launcher = subprocess.Popen([self.binary.name[:30], self.config_name], executable=str(self.binary),
+                                        cwd=self.root, stdin=subprocess.DEVNULL,
                                         stdout=out, stderr=subprocess.STDOUT, env=env, preexec_fn=_pre)
         finally:
             out.close()
