@@ -87,6 +87,7 @@ static int g_server_pids[MAX_SERVERS], g_nservers;
 static uint64_t g_expect_lines, g_expect_warm;
 static int g_cpus[256], g_ncpus;
 static int g_verbose;
+static double g_stall_s = 30.0;  /* no new line for this long in a closed-loop phase = a lost line: fail loudly */
 static int g_quiet_ms = 40;   /* drain until every socket of the worker has been silent this long */
 static int g_quickack = 1; /* re-arm TCP_QUICKACK after every read: the talker never sets TCP_NODELAY, so a second
                               small write to the same socket waits (Nagle) for our ACK, which the kernel would
@@ -100,7 +101,7 @@ static atomic_int g_drained_workers;
 static atomic_ullong g_lines, g_bytes, g_acks;
 static atomic_ullong g_t_end;
 static atomic_int g_done, g_fail;
-static pthread_barrier_t g_run_barrier;
+static pthread_barrier_t g_run_barrier, g_warm_barrier;
 
 static uint64_t now_ns(void) {
     struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -132,6 +133,7 @@ static void parse_spec(FILE *fp) {
         else if (!strncmp(line, "timeout_s ", 10)) g_timeout_s = atof(line + 10);
         else if (!strncmp(line, "verbose ", 8)) g_verbose = atoi(line + 8);
         else if (!strncmp(line, "drain_quiet_ms ", 15)) g_quiet_ms = atoi(line + 15);
+        else if (!strncmp(line, "stall_s ", 8)) g_stall_s = atof(line + 8);
         else if (!strncmp(line, "spin ", 5)) g_spin = atoi(line + 5);
         else if (!strncmp(line, "quickack ", 9)) g_quickack = atoi(line + 9);
         else if (!strncmp(line, "expect_lines ", 13)) g_expect_lines = strtoull(line + 13, NULL, 10);
@@ -427,6 +429,9 @@ static void *worker_main(void *arg) {
                 c->st = ST_RUN; c->llen = 0; c->rx_lines = c->rx_bytes = c->rx_acks = 0; c->cur = &c->warm;
             }
             started_warm = 1; started_run = 1; pub_lines = pub_bytes = pub_acks = 0;
+            /* nobody may send before EVERY worker has stopped discarding: a broadcast reaching a
+               client whose worker is still draining would be thrown away and the count never met */
+            pthread_barrier_wait(&g_warm_barrier);
             for (int i = 0; i < w->ncl; i++) send_next(w->cl[i]);
             continue;
         }
@@ -618,6 +623,7 @@ int main(int argc, char **argv) {
         g_clients[i].thread = w->id; w->cl[w->ncl++] = &g_clients[i];
     }
     pthread_barrier_init(&g_run_barrier, NULL, (unsigned)g_nthreads + 1);
+    pthread_barrier_init(&g_warm_barrier, NULL, (unsigned)g_nthreads);
     uint64_t t_login0 = now_ns();
     for (int t = 0; t < g_nthreads; t++) pthread_create(&g_workers[t].tid, NULL, worker_main, &g_workers[t]);
 
@@ -633,8 +639,15 @@ int main(int argc, char **argv) {
     if (!atomic_load(&g_fail) && g_expect_warm) {
         uint64_t w0 = now_ns();
         atomic_store(&g_phase, 4);
+        uint64_t seen = 0, seen_at = now_ns();
         while (atomic_load(&g_lines) < g_expect_warm && !atomic_load(&g_fail)) {
-            if (now_ns() > deadline) { fprintf(stderr, "loadgen: warm-up timed out\n"); atomic_store(&g_fail, 1); }
+            uint64_t l = atomic_load(&g_lines), n = now_ns();
+            if (l != seen) { seen = l; seen_at = n; }
+            if (n > deadline || (double)(n - seen_at) > g_stall_s * 1e9) {
+                fprintf(stderr, "loadgen: warm-up %s at %llu/%llu lines\n", n > deadline ? "timed out" : "stalled",
+                        (unsigned long long)l, (unsigned long long)g_expect_warm);
+                atomic_store(&g_fail, 1);
+            }
             usleep(500);
         }
         warm_s = (double)(now_ns() - w0) / 1e9;
@@ -653,6 +666,16 @@ int main(int argc, char **argv) {
             usleep(500);
             uint64_t n = now_ns();
             if (n > deadline) { timed_out = 1; break; }
+            {
+                static uint64_t seen, seen_at;
+                uint64_t l = atomic_load(&g_lines);
+                if (!seen_at || l != seen) { seen = l; seen_at = n; }
+                if ((double)(n - seen_at) > g_stall_s * 1e9) {
+                    fprintf(stderr, "loadgen: stalled at %llu/%llu lines for %.0f s\n", (unsigned long long)l,
+                            (unsigned long long)g_expect_lines, g_stall_s);
+                    timed_out = 1; break;
+                }
+            }
             if (g_verbose && n - last_prog > 1000000000ull) {
                 uint64_t l = atomic_load(&g_lines);
                 fprintf(stderr, "loadgen: %llu/%llu lines (+%llu)\n", (unsigned long long)l,
