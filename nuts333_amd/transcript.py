@@ -77,6 +77,79 @@ class Client:
         self.sock.sendall(data)
 
 
+class Peer:
+    """A scripted NUTS-netlink endpoint: plays the *other talker* on a link, byte for byte.
+
+    Either dials the talker's link port (the talker then runs accept_server_connection,
+    ``nuts333.c:2892-2942``) or listens and is dialled by a talker booted with
+    ``auto_connect YES`` (``nuts333.c:1200-1274``).  Everything it receives is recorded, so the
+    fixtures pin the wire protocol itself, not just its effect on telnet clients."""
+
+    def __init__(self, key: str):
+        self.key = key
+        self.lsock = socket.socket()
+        self.lsock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        self.lsock.bind(("127.0.0.1", 0))
+        self.lsock.listen(4)
+        self.port = self.lsock.getsockname()[1]
+        self.sock: socket.socket | None = None
+        self.buf = bytearray()
+
+    def dial(self, port: int) -> None:
+        self.sock = socket.create_connection(("127.0.0.1", port))
+        self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+
+    def accept(self, timeout: float = 10.0) -> None:
+        self.lsock.settimeout(timeout)
+        self.sock, _ = self.lsock.accept()
+        self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+
+    def send(self, data: bytes) -> None:
+        self.sock.sendall(data)
+
+    def expect(self, suffix: bytes, timeout: float = 10.0) -> bytes:
+        deadline = time.monotonic() + timeout
+        while not bytes(self.buf).endswith(suffix):
+            left = deadline - time.monotonic()
+            if left <= 0:
+                raise ScriptError(f"peer {self.key}: timed out waiting for {suffix!r}; have {bytes(self.buf)!r}")
+            r, _, _ = select.select([self.sock], [], [], left)
+            if r:
+                d = self.sock.recv(65536)
+                if not d:
+                    if suffix == b"" or bytes(self.buf).endswith(suffix):
+                        break
+                    raise ScriptError(f"peer {self.key}: link closed; have {bytes(self.buf)!r}")
+                self.buf += d
+        out = bytes(self.buf)
+        self.buf.clear()
+        return out
+
+    def expect_close(self, timeout: float = 10.0) -> bytes:
+        """Read until the talker closes the link."""
+        deadline = time.monotonic() + timeout
+        while True:
+            left = deadline - time.monotonic()
+            if left <= 0:
+                raise ScriptError(f"peer {self.key}: link still open; have {bytes(self.buf)!r}")
+            r, _, _ = select.select([self.sock], [], [], left)
+            if r:
+                d = self.sock.recv(65536)
+                if not d:
+                    out = bytes(self.buf)
+                    self.buf.clear()
+                    return out
+                self.buf += d
+
+    def close(self) -> None:
+        for s in (self.sock, self.lsock):
+            try:
+                if s is not None:
+                    s.close()
+            except OSError:
+                pass
+
+
 class Session:
     """Drive several clients against one (or two) talkers and record what each receives."""
 
@@ -84,7 +157,45 @@ class Session:
         self.host, self.default_port = host, default_port
         self.talker_ports = talker_ports or [default_port]
         self.clients: dict[str, Client] = {}
+        self.peers: dict[str, Peer] = {}
         self.steps: list[dict] = []
+
+    # -- netlink peers -----------------------------------------------------------------
+    def peer_step(self, key: str, send: bytes, expect: bytes | None, note: str = "", closes: bool = False,
+                  client_expect: dict[str, bytes] | None = None) -> None:
+        """The scripted peer sends ``send`` on the link and reads until ``expect`` (or until the
+        talker closes the link); then every telnet client is synced.  Clients that cannot be
+        synced (away over this very link) are read up to the suffix in ``client_expect``."""
+        p = self.peers[key]
+        if send:
+            p.send(send)
+        got = p.expect_close() if closes else (p.expect(expect) if expect is not None else b"")
+        pre = {k: self.clients[k].read_until(v) for k, v in (client_expect or {}).items()}
+        recv = self._collect(None)
+        for k, v in pre.items():
+            recv[k] = v + recv.get(k, b"")
+        recv[key] = got
+        what = {"op": "peer", "actor": key, "send": send.decode("latin-1")}
+        if note:
+            what["note"] = note
+        self._record(what, recv)
+
+    def send_only(self, key: str, text: str, peer_expect: dict[str, bytes], note: str = "") -> None:
+        """A line whose only effect is on the link (the actor, away on the other talker, gets no
+        output of his own): record what the peers receive."""
+        self.clients[key].send_raw(text.encode("latin-1") + b"\n")
+        got = {k: self.peers[k].expect(v) for k, v in peer_expect.items()}
+        recv = self._collect(None)
+        recv.update(got)
+        what = {"op": "line", "actor": key, "send": text}
+        if note:
+            what["note"] = note
+        self._record(what, recv)
+
+    def peer_expect(self, key: str, suffix: bytes) -> None:
+        """Append what the peer has received (up to ``suffix``) to the last recorded step."""
+        got = normalise(self.peers[key].expect(suffix)).decode("latin-1")
+        self.steps[-1]["recv"][key] = self.steps[-1]["recv"].get(key, "") + got
 
     # -- plumbing ----------------------------------------------------------------------
     def _record(self, what: dict, recv: dict[str, bytes]) -> None:
@@ -255,3 +366,6 @@ class Session:
             except OSError:
                 pass
         self.clients.clear()
+        for p in self.peers.values():
+            p.close()
+        self.peers.clear()

@@ -15,7 +15,7 @@ from typing import Sequence
 
 from nuts333_amd import provision as pv
 from nuts333_amd.talker import Talker, free_ports
-from nuts333_amd.transcript import Session
+from nuts333_amd.transcript import Peer, Session
 
 import scenarios
 
@@ -35,8 +35,12 @@ def run_scenario(name: str, binaries: Path | Sequence[Path]) -> dict:
     talkers: list[Talker | None] = [None] * n
     with tempfile.TemporaryDirectory(prefix=f"scn_{name}_") as tmp:
         ports = [free_ports(3) for _ in range(n)]
-        cfgs = spec["configs"](ports)
         sess = Session(ports[0][0], talker_ports=[p[0] for p in ports])
+        sess.link_ports = [p[2] for p in ports]
+        # scripted netlink peers listen before any talker boots (a talker with auto_connect dials at boot)
+        for key in spec.get("peers", []):
+            sess.peers[key] = Peer(key)
+        cfgs = spec["configs"](ports, {k: p.port for k, p in sess.peers.items()}) if spec.get("peers") else spec["configs"](ports)
         try:
             for i in spec["boot_order"]:
                 root = Path(tmp) / f"t{i}"

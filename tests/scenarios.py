@@ -312,6 +312,97 @@ def netlink():
             "wait_syslog": [(0, "Connection to talker2 verified")], "script": script}
 
 
+def netlink_wire_accept():
+    """A scripted peer dials the talker and speaks the netlink protocol to it, verb by verb."""
+    accounts = [_acc(B), _acc(C)]
+
+    def configs(p, peer_ports):
+        return [pv.TalkerConfig(mainport=p[0][0], wizport=p[0][1], linkport=p[0][2], max_users=50, verification="verify0",
+                                sites=[pv.Site("peer1", "localhost", 1, "verify1"), pv.Site("peer1", "127.0.0.1", 1, "verify1")])]
+
+    def script(s):
+        s.connect("b"); s.login("b", B)
+        for hop in pv.WALKS["lounge"]:
+            s.line("b", f".go {hop}")
+        s.peers["p"].dial(s.link_ports[0])
+        s.peer_step("p", b"", b"GRANTED CONNECT\n", note="accept_server_connection: version greeting, then grant")
+        s.peer_step("p", b"VERIFICATION verify1 3.3.3\n", b"VERIFY OK ALL\n")
+        s.peer_step("p", b"TRANS Alice NUKyNCCLvgLH. 1 is alice\n", b"GRANTED Alice\n", note="no local account: description and level come from the frame")
+        s.peer_step("p", b"ACT Alice look\n", b"PRM Alice\n", note="one MSG..EMSG frame per write_user call, then PRM")
+        s.peer_step("p", b"ACT Alice say hello there\n", b"PRM Alice\n")
+        s.peer_step("p", b"ACT Alice .shout loud and clear\n", b"PRM Alice\n")
+        s.peer_step("p", b"ACT Alice .tell bobby psst?\n", b"PRM Alice\n")
+        s.line("b", ".tell alice back at you"); s.peer_expect("p", b"EMSG\n")
+        s.line("b", "a room say reaches the remote user"); s.peer_expect("p", b"EMSG\n")
+        s.line("b", "~FRmarkup~RS crosses the link unexpanded"); s.peer_expect("p", b"EMSG\n")
+        s.peer_step("p", b"ACT Alice NL\nACT Alice .version\n", b"PRM Alice\n", note="two frames in one segment; NL produces nothing")
+        s.peer_step("p", b"ACT Alice say par", None, note="a line split over two segments is buffered")
+        s.peer_step("p", b"tial line\n", b"PRM Alice\n")
+        s.peer_step("p", b"KA\nFOO bar\n", b"ERROR\n", note="keepalive is silent; an unknown verb is answered with ERROR")
+        s.peer_step("p", b"TRANS Alice x 1 again\n", b"DENIED Alice 5\n", note="already here")
+        s.peer_step("p", b"ACT Nobody look\n", b"DENIED Nobody 8\n")
+        s.peer_step("p", b"TRANS Carol wronghash 1 has an account here\n", b"DENIED Carol 7\n", note="local account, password mismatch")
+        s.peer_step("p", b"TRANS Dave somehash 4 is a god elsewhere\n", b"GRANTED Dave\n", note="level capped at rem_user_maxlevel")
+        s.peer_step("p", b"ACT Dave .invis\n", b"PRM Dave\n", note="capped to WIZ: .invis needs ARCH")
+        s.peer_step("p", b"ACT Dave .passwd\n", b"PRM Dave\n", note="barred for remote users")
+        s.peer_step("p", b"MSG Bobby\nrelayed line one\nrelayed line two\nEMSG\nACT Alice .version\n", b"PRM Alice\n",
+                    note="MSG body is relayed line by line to the named user")
+        s.peer_step("p", b"REL Dave\nACT Alice .version\n", b"PRM Alice\n")
+        s.peer_step("p", b"DISCONNECT\n", None, closes=True, note="remote users vanish, the link is closed")
+        s.line("b", "after the link went down")
+
+    return {"configs": configs, "accounts": [accounts], "boot_order": [0], "peers": ["p"], "script": script}
+
+
+def netlink_wire_dial():
+    """The talker dials a scripted peer at boot (auto_connect) and a local user travels out and back."""
+    accounts = [_acc(A), _acc(D)]
+    look_end = b"has been set yet.\n\r"
+
+    def configs(p, peer_ports):
+        rooms1 = tuple(pv.Room(r.label, r.name, r.links, r.access, "CONNECT peer2" if r.name == "drive" else "",
+                               r.description) for r in pv.DEFAULT_ROOMS)
+        return [pv.TalkerConfig(mainport=p[0][0], wizport=p[0][1], linkport=p[0][2], max_users=50, verification="verify1",
+                                auto_connect=True, rooms=rooms1, sites=[pv.Site("peer2", "127.0.0.1", peer_ports["p"], "verify2")])]
+
+    def script(s):
+        p = s.peers["p"]
+        p.accept()
+        s.connect("a"); s.login("a", A)
+        s.connect("d"); s.login("d", D)
+        s.peer_step("p", b"NUTS 3.3.3\nGRANTED CONNECT\n", b"\n", note="the dialler answers the grant with its verification")
+        s.peer_step("p", b"VERIFY OK ALL\n", None, note="link up: announced to everyone")
+        s.line("a", ".look")
+        s.send_only("a", ".go peer2", {"p": b"\n"}, note="TRANS <name> <hash> <level> <desc>")
+        s.set_flags("a", can_sync=False)
+        s.peer_step("p", b"GRANTED Alice\n", b"ACT Alice look\n", client_expect={"a": b"cyberspace...\n\r"})
+        s.peer_step("p", b"MSG Alice\n\n~FTRoom: ~FGelsewhere\n\nEMSG\nMSG Alice\nno newline at the end of this frame\nEMSG\nPRM Alice\n", None,
+                    client_expect={"a": b"end of this frame\n\r"})
+        s.send_only("a", "hello remote", {"p": b"\n"})
+        s.send_only("a", "is this relayed?", {"p": b"\n"})
+        s.send_only("a", ".shout x y", {"p": b"\n"})
+        s.send_only("a", ";emotes", {"p": b"\n"})
+        s.send_only("a", "> bobby hi", {"p": b"\n"})
+        s.send_only("a", "", {"p": b"\n"}, note="an empty line travels as NL")
+        s.send_only("a", ".bogus", {"p": b"\n"}, note="unknown commands are relayed too: the remote decides")
+        s.line("d", ".tell alice are you there")
+        s.peer_step("p", b"REMVD Alice\n", None, client_expect={"a": look_end}, note="sent home")
+        s.set_flags("a", can_sync=True)
+        s.line("a", "back home")
+        s.send_only("a", ".go peer2 secret", {"p": b"\n"}, note="explicit remote password is crypt()ed into the frame")
+        s.peer_step("p", b"DENIED Alice 7\n", None, client_expect={"a": b"password>'.\n\r"})
+        s.send_only("a", ".go peer2", {"p": b"\n"})
+        s.line("a", ".go peer2", note="still waiting for the grant")
+        s.line("a", ".go hallway", expect=look_end, note="gives up: REL goes out")
+        s.peer_expect("p", b"\n")
+        s.line("a", ".go drive")
+        s.peer_step("p", b"DISCONNECT\n", None, closes=True)
+        s.line("a", ".go peer2")
+
+    return {"configs": configs, "accounts": [accounts], "boot_order": [0], "peers": ["p"],
+            "wait_syslog": [(0, "Connected to peer2")], "script": script}
+
+
 SCENARIOS = {
     "speech_colour_off": speech_colour_off,
     "speech_colour_mixed": speech_colour_mixed,
@@ -323,4 +414,6 @@ SCENARIOS = {
     "review": review,
     "prompts": prompts,
     "netlink": netlink,
+    "netlink_wire_accept": netlink_wire_accept,
+    "netlink_wire_dial": netlink_wire_dial,
 }
