@@ -156,6 +156,7 @@ class Session:
     def __init__(self, default_port: int, host: str = "127.0.0.1", talker_ports: list[int] | None = None):
         self.host, self.default_port = host, default_port
         self.talker_ports = talker_ports or [default_port]
+        self.wiz_ports: list[int] = []
         self.clients: dict[str, Client] = {}
         self.peers: dict[str, Peer] = {}
         self.steps: list[dict] = []
@@ -237,13 +238,60 @@ class Session:
             out += d
 
     # -- steps -------------------------------------------------------------------------
-    def connect(self, key: str, talker: int = 0) -> None:
-        s = socket.create_connection((self.host, self.talker_ports[talker]))
+    def connect(self, key: str, talker: int = 0, wizport: bool = False, expect: bytes = b"Give me a name: ",
+                closes: bool = False) -> None:
+        port = self.wiz_ports[talker] if wizport else self.talker_ports[talker]
+        s = socket.create_connection((self.host, port))
         s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
         c = Client(key, s)
-        self.clients[key] = c
-        banner = c.read_until(b"Give me a name: ")
-        self._record({"op": "connect", "actor": key}, {key: banner})
+        if closes:
+            banner = self._read_to_close(c)
+            s.close()
+        else:
+            self.clients[key] = c
+            banner = c.read_until(expect)
+        self._record({"op": "connect", "actor": key, **({"note": "wizport"} if wizport else {})}, {key: banner})
+
+    @staticmethod
+    def _read_to_close(c: Client, timeout: float = 10.0) -> bytes:
+        deadline = time.monotonic() + timeout
+        while True:
+            left = deadline - time.monotonic()
+            if left <= 0:
+                raise ScriptError(f"client {c.key}: server did not close; have {bytes(c.buf)!r}")
+            r, _, _ = select.select([c.sock], [], [], left)
+            if r:
+                try:
+                    d = c.sock.recv(65536)
+                except ConnectionResetError:
+                    d = b""
+                if not d:
+                    out = bytes(c.buf)
+                    c.buf.clear()
+                    return out
+                c.buf += d
+
+    def dialog(self, key: str, send: str, expect: bytes | None = None, closes: bool = False, note: str = "",
+               logged_in: bool | None = None, **flags) -> None:
+        """Pre-login conversation: send one line, read up to ``expect`` (or to the close)."""
+        c = self.clients[key]
+        c.send_raw(send.encode("latin-1") + b"\n")
+        if closes:
+            mine = self._read_to_close(c)
+            c.sock.close()
+            del self.clients[key]
+        else:
+            mine = c.read_until(expect)
+        if logged_in is not None and not closes:
+            c.logged_in = logged_in
+        if flags:
+            self.set_flags(key, **flags)
+        recv = self._collect(None) if not closes or self.clients else {}
+        recv[key] = mine + recv.get(key, b"")
+        what = {"op": "dialog", "actor": key, "send": send}
+        if note:
+            what["note"] = note
+        self._record(what, recv)
 
     def login(self, key: str, name: str, password: str = "test", colour: bool = False,
               sync_suffix: bytes = b"", prompt_re: bytes = b"") -> None:

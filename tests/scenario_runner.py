@@ -25,7 +25,8 @@ def run_scenario(name: str, binaries: Path | Sequence[Path]) -> dict:
     if isinstance(spec, tuple):
         cfg_kw, accounts, script = spec
         spec = {
-            "configs": lambda p: [pv.TalkerConfig(mainport=p[0][0], wizport=p[0][1], linkport=p[0][2], max_users=50, **cfg_kw)],
+            "configs": lambda p: [pv.TalkerConfig(mainport=p[0][0], wizport=p[0][1], linkport=p[0][2],
+                                                  **{"max_users": 50, **cfg_kw})],
             "accounts": [accounts], "boot_order": [0], "script": script, "config_kw": cfg_kw,
         }
     n = len(spec["accounts"])
@@ -37,6 +38,7 @@ def run_scenario(name: str, binaries: Path | Sequence[Path]) -> dict:
         ports = [free_ports(3) for _ in range(n)]
         sess = Session(ports[0][0], talker_ports=[p[0] for p in ports])
         sess.link_ports = [p[2] for p in ports]
+        sess.wiz_ports = [p[1] for p in ports]
         # scripted netlink peers listen before any talker boots (a talker with auto_connect dials at boot)
         for key in spec.get("peers", []):
             sess.peers[key] = Peer(key)
@@ -45,12 +47,24 @@ def run_scenario(name: str, binaries: Path | Sequence[Path]) -> dict:
             for i in spec["boot_order"]:
                 root = Path(tmp) / f"t{i}"
                 pv.write_tree(root, cfgs[i], spec["accounts"][i])
+                for rel, content in spec.get("files", {}).items():
+                    (root / rel).write_text(content)
                 talkers[i] = Talker(binaries[i], root)
                 talkers[i].start()
             for i, needle in spec.get("wait_syslog", []):
                 talkers[i].wait_syslog(needle)
             spec["script"](sess)
             alive = [t.alive() for t in talkers]
+            sess.shutdown()
+            # on-disk side effects the scenario wants pinned (user records written at logout)
+            files = {}
+            for rel in spec.get("collect_files", []):
+                path = Path(tmp) / "t0" / rel
+                deadline = __import__("time").monotonic() + 5
+                while not path.exists() and __import__("time").monotonic() < deadline:
+                    __import__("time").sleep(0.02)
+                __import__("time").sleep(0.1)
+                files[rel] = scenarios.mask_user_record(path.read_text()) if path.exists() else None
         finally:
             sess.shutdown()
             for t in talkers:
@@ -63,4 +77,5 @@ def run_scenario(name: str, binaries: Path | Sequence[Path]) -> dict:
         "config": spec.get("config_kw", {}),
         "accounts": [[asdict(a) for a in accs] for accs in spec["accounts"]],
         "steps": sess.steps,
+        **({"files": files} if spec.get("collect_files") else {}),
     }

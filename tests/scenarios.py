@@ -14,14 +14,31 @@ What they pin, by reference function:
   framing       terminate, char-mode assembly, pipelining drop, "." repeat      c:136-175, 369-411
   review        record / record_tell ring buffers                               c:2062-2082
   prompt        prompt() in speech and command mode                             c:2174-2197
+  rooms         go / move_user / look: adjacency, prefix names, teleport, private     c:3942-4004, 4305-4459, 2412-2421
+                rooms, invisible movement
+  login_paths   accept + 3-stage login incl. every error exit, new account, wizport,   c:263-311, 1451-1606, 1645-1673
+                ban list, hung-login takeover; the .D record written at logout
+  capacity      max_users on the main port only                                        c:287-291
   netlink       two talkers: TRANS/GRANTED, ACT relay, MSG..EMSG frames, PRM,   c:2946-3073, 3077-3285, 1299-1306,
                 REMVD on the way home, offsite tell, home execution               3452-3479, 3787-3806, 4168-4172
+  netlink_wire_* a scripted peer speaks the link protocol itself: every verb's    c:2892-2942, 2946-3073, 3077-3479,
+                bytes in both directions, split/merged segments, denials, link     3689-3746, 4305-4375
+                shutdown
 """
 from __future__ import annotations
 
 from nuts333_amd import provision as pv
 
 A, B, C, D = "Alice", "Bobby", "Carol", "Dave"
+
+
+def mask_user_record(text: str) -> str:
+    """A saved .D record with its four wall-clock fields masked (DOCS/userdata_format:7-15)."""
+    lines = text.split("\n")
+    if len(lines) > 1:
+        f = lines[1].split(" ")
+        lines[1] = " ".join(["T"] * 4 + f[4:])
+    return "\n".join(lines)
 
 
 def _acc(name, **kw):
@@ -261,6 +278,113 @@ def prompts():
     return {}, accounts, script
 
 
+def rooms():
+    """go / move_user / look and who hears what while people move (nuts333.c:3942-4004, 4305-4459)."""
+    accounts = [_acc(A), _acc(B, level=2), _acc(C, level=3), _acc(D, in_phrase="bounces in", out_phrase="rolls out")]
+
+    def script(s):
+        for k, n in (("a", A), ("b", B), ("c", C), ("d", D)):
+            s.connect(k); s.login(k, n)
+        s.line("a", ".go")
+        s.line("a", ".go nowhere")
+        s.line("a", ".go drive")
+        s.line("a", ".go lounge", note="not adjoined, and a USER cannot teleport")
+        s.line("a", ".go ha", note="room names match by prefix")
+        s.line("d", ".go hallway", note="custom in/out phrases")
+        s.line("a", ".go wizroom", note="fixed-private: below WIZ stays out")
+        s.line("b", ".go wizroom", note="a WIZ teleports to a room that is not adjoined")
+        s.line("b", ".go lounge")
+        s.line("c", ".invis")
+        s.line("c", ".go hallway", note="invisible movement")
+        s.line("a", ".look", note="an invisible ARCH is hidden from a USER")
+        s.line("c", ".look")
+        s.line("b", ".go hallway")
+        s.line("b", ".look", note="... and from a WIZ")
+        s.line("c", ".vis")
+        s.line("a", ".look")
+        s.line("a", "said in the hallway")
+        s.line("c", ".go drive")
+        s.line("c", "alone in the drive")
+
+    return {}, accounts, script
+
+
+def login_paths():
+    """accept_connection + the three login stages, error paths included (nuts333.c:263-311, 1451-1606)."""
+    accounts = [_acc(A), _acc(B, level=0), _acc(D, level=4)]
+    name_prompt = b"Give me a name: "
+    iac_on = b"\xff\xfc\x01"
+    pw_prompt = b"Give me a password: \xff\xfb\x01"
+    look_end = b"has been set yet.\n\r"
+
+    def script(s):
+        s.connect("x")
+        s.dialog("x", "", name_prompt, note="empty name")
+        s.dialog("x", "version", name_prompt)
+        s.dialog("x", "ab", name_prompt + iac_on, note="too short: attempt 1")
+        s.dialog("x", "abcdefghijklm", name_prompt + iac_on, note="too long: attempt 2")
+        s.dialog("x", "r2d2", closes=True, note="not letters: attempt 3 -> dropped")
+        s.connect("x")
+        s.dialog("x", "quit", closes=True)
+        s.connect("x")
+        s.dialog("x", "  alice   trailing words ignored", pw_prompt, note="first word only; case kept, first letter raised")
+        s.dialog("x", "ab", name_prompt + iac_on, note="password too short")
+        s.dialog("x", "alice", pw_prompt)
+        s.dialog("x", "wrongpassword", name_prompt + iac_on, note="incorrect login")
+        s.dialog("x", "alice", pw_prompt)
+        s.dialog("x", "test", look_end, logged_in=True, note="third attempt succeeds")
+        # a hung login of the same name is cleared when somebody else types that name
+        s.connect("h")
+        s.dialog("h", "bobby", pw_prompt)
+        s.connect("y")
+        s.dialog("y", "bobby", pw_prompt, note="the other half-open Bobby is dropped")
+        s.dialog("y", "test", look_end, logged_in=True)
+        # new account
+        s.connect("n")
+        s.dialog("n", "newbie", b"Give me a password: \xff\xfb\x01", note="unknown name: new user")
+        s.dialog("n", "secret", b"confirm password: ")
+        s.dialog("n", "secreX", name_prompt + iac_on, note="confirmation mismatch")
+        s.dialog("n", "newbie", pw_prompt)
+        s.dialog("n", "secret", b"confirm password: ")
+        s.dialog("n", "secret", look_end, logged_in=True, note="created at level NEW")
+        s.line("n", "a new user may speak")
+        s.line("n", ".shout but not shout")
+        # wizport
+        s.connect("w", wizport=True)
+        s.dialog("w", "alice", closes=True, note="USER on the wizport")
+        s.connect("w", wizport=True)
+        s.dialog("w", "nosuchuser", closes=True, note="no new accounts on the wizport")
+        s.connect("w", wizport=True, expect=b"** Wizport login **\n\r\n\r\xff\xfc\x01" + name_prompt)
+        s.dialog("w", "dave", pw_prompt)
+        s.dialog("w", "test", look_end, logged_in=True)
+        # banned name
+        s.connect("z")
+        s.dialog("z", "Mallory", closes=True, note="listed in datafiles/userban")
+        s.close("n")
+
+    return {"configs": lambda p: [pv.TalkerConfig(mainport=p[0][0], wizport=p[0][1], linkport=p[0][2], max_users=50)],
+            "accounts": [accounts], "boot_order": [0], "script": script,
+            "files": {"datafiles/userban": "Mallory\n"}, "collect_files": ["userfiles/Newbie.D", "userfiles/Alice.D"]}
+
+
+def capacity():
+    """max_users applies to the main port only, counting half-open logins (nuts333.c:287-291)."""
+    accounts = [_acc(A), _acc(B), _acc(D, level=4)]
+    look_end = b"has been set yet.\n\r"
+    pw_prompt = b"Give me a password: \xff\xfb\x01"
+
+    def script(s):
+        s.connect("a"); s.login("a", A)
+        s.connect("h")                                  # half-open login: counts
+        s.connect("c", closes=True)                     # third: full
+        s.connect("w", wizport=True, expect=b"Give me a name: ")   # the wizport is exempt
+        s.dialog("w", "dave", pw_prompt)
+        s.dialog("w", "test", look_end, logged_in=True)
+        s.line("a", "two users and a half-open login")
+
+    return {"max_users": 2}, accounts, script
+
+
 def netlink():
     """talker 0 ("talker1") dials talker 1 ("talker2") at boot; Alice travels there and back."""
     acc1 = [_acc(A), _acc(D)]
@@ -413,6 +537,9 @@ SCENARIOS = {
     "framing": framing,
     "review": review,
     "prompts": prompts,
+    "rooms": rooms,
+    "login_paths": login_paths,
+    "capacity": capacity,
     "netlink": netlink,
     "netlink_wire_accept": netlink_wire_accept,
     "netlink_wire_dial": netlink_wire_dial,

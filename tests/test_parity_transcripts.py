@@ -43,17 +43,20 @@ def test_every_scenario_has_a_fixture():
 
 @pytest.mark.parametrize("name", NAMES)
 def test_port_matches_golden(name, port_binary):
-    gold = _load(name)["steps"]
-    got = run_scenario(name, port_binary)["steps"]
-    assert got == gold, _diff(gold, got)
+    gold = _load(name)
+    got = run_scenario(name, port_binary)
+    assert got["steps"] == gold["steps"], _diff(gold["steps"], got["steps"])
+    # user records written to disk at logout (save_user_details, nuts333.c:1645-1673), clock fields masked
+    assert got.get("files") == gold.get("files")
 
 
 @pytest.mark.reference
 @pytest.mark.parametrize("name", NAMES)
 def test_reference_still_matches_golden(name, ref_binary):
-    gold = _load(name)["steps"]
-    got = run_scenario(name, ref_binary)["steps"]
-    assert got == gold, _diff(gold, got)
+    gold = _load(name)
+    got = run_scenario(name, ref_binary)
+    assert got["steps"] == gold["steps"], _diff(gold["steps"], got["steps"])
+    assert got.get("files") == gold.get("files")
 
 
 @pytest.mark.reference
@@ -70,6 +73,7 @@ def test_fixtures_contain_no_reference_source():
     """A fixture is data: provisioning, inputs, received bytes -- nothing else."""
     for p in GOLDEN.glob("*.json"):
         d = json.loads(p.read_text())
-        assert set(d) == {"scenario", "config", "accounts", "steps"}
+        assert set(d) <= {"scenario", "config", "accounts", "steps", "files"}
         for st in d["steps"]:
             assert set(st) <= {"op", "actor", "name", "send", "note", "recv"}
+            assert st["op"] in {"connect", "login", "line", "raw", "close", "dialog", "peer"}
