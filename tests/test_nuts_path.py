@@ -193,3 +193,13 @@ def test_record_ring(lib):
     assert slot(0) == b"line 5\n" and slot(1) == b"line 6\n" and slot(2) == b"line 2\n"
     lib.np_record(ring, 5, ctypes.byref(rev), b"y" * 250 + b"\n")
     assert slot(2) == b"y" * 200 + b"\n"                          # cut at 200, newline forced (c:2066-2068)
+
+
+# ---------------------------------------------------------------- ABI surface
+def test_library_exports_every_declared_symbol(lib):
+    """oracle/nuts_path.h is the only C header in the repo; the .so must export all of it."""
+    header = (REPO / "oracle" / "nuts_path.h").read_text()
+    declared = sorted(set(re.findall(r"\b(np_[a-z_]+)\s*\(", header)) - {"np_emit_fn"})
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in nuts_path.h but not exported"
