@@ -708,7 +708,10 @@ int main(int argc, char **argv) {
     size_t nlat = 0;
     for (int t = 0; t < g_nthreads; t++) nlat += g_workers[t].nlat;
     uint64_t *lat = malloc(sizeof(uint64_t) * (nlat ? nlat : 1)); size_t k = 0;
-    for (int t = 0; t < g_nthreads; t++) { memcpy(lat + k, g_workers[t].lat, sizeof(uint64_t) * g_workers[t].nlat); k += g_workers[t].nlat; }
+    for (int t = 0; t < g_nthreads; t++) {
+        if (g_workers[t].nlat) memcpy(lat + k, g_workers[t].lat, sizeof(uint64_t) * g_workers[t].nlat);
+        k += g_workers[t].nlat;
+    }
     qsort(lat, nlat, sizeof(uint64_t), cmp_u64);
     double lat_mean = 0; for (size_t i = 0; i < nlat; i++) lat_mean += (double)lat[i];
     if (nlat) lat_mean /= (double)nlat;

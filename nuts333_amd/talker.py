@@ -33,7 +33,24 @@ _BOOT_RE = re.compile(r"Booted successfully with PID (\d+)")
 
 
 def free_ports(n: int = 3) -> list[int]:
-    """n distinct currently-free loopback TCP ports."""
+    """n distinct currently-free loopback TCP ports.  Under a multi-rank launch (RANK set) each rank
+    draws from its own 400-port window, so replicas booted at the same instant cannot pick the same
+    port between our probe and the talker's bind()."""
+    rank = os.environ.get("RANK")
+    if rank is not None and rank.isdigit():
+        base = 20000 + (int(rank) % 100) * 400
+        ports: list[int] = []
+        start = int.from_bytes(os.urandom(2), "little") % 400
+        for k in range(400):
+            p = base + (start + k) % 400
+            with socket.socket() as s:
+                try:
+                    s.bind(("127.0.0.1", p))
+                except OSError:
+                    continue
+            ports.append(p)
+            if len(ports) == n:
+                return ports
     socks, ports = [], []
     try:
         for _ in range(n):
