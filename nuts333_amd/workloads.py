@@ -128,7 +128,12 @@ def run_spec(spec: Spec, talkers: Sequence[Talker], *, timeout_s: float = 600.0,
     server_cpus = {t.cpu for t in talkers if t.cpu is not None}
     client_cpus = [c for c in cpus if c not in server_cpus] if pin else []
     if threads is None:
-        threads = max(1, min(len(client_cpus) or len(cpus) - 1 or 1, 14, len(spec.clients)))
+        # Few receiver threads, on cores next to the talker's: with loopback TCP the talker's write(2)
+        # touches cache lines last used by the receiving core, so spreading receivers over many cores
+        # (or a second CCD) inflates the *server's* CPU per line by ~45 % (1.38 -> 2.0+ us on an EPYC
+        # 9575F, profiles/sweep_loadgen_threads_r01_mi355xhost.log).  2-7 threads measure the same; 1 is
+        # client-bound.  4 is the portable choice.
+        threads = max(1, min(len(client_cpus) or len(cpus) - 1 or 1, 4, len(spec.clients)))
     # the talker listens with backlog 10 (nuts333.c:1189): keep concurrent logins below it
     login_window = max(1, 8 // threads)
     # talker<->talker traffic sits behind Nagle + delayed ACK (neither side sets TCP_NODELAY): wait longer
