@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Rewrite BASELINE.md section 2 (between the FORMAL markers) from the JSON files under profiles/."""
+from __future__ import annotations
+
+import json
+import re
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+P = REPO / "profiles"
+
+
+def table(name: str) -> str:
+    lines = [l for l in (P / name).read_text().splitlines() if l.strip()]
+    return lines[0] + "\n\n" + "\n".join(lines[1:])
+
+
+def main() -> None:
+    b = json.loads((P / "bench_r01_n1_mi355xhost.json").read_text())
+    b4 = json.loads((P / "bench_r01_config4_mi355xhost.json").read_text())
+    r2 = json.loads((P / "bench_r01_replicas2_mi355xhost.json").read_text())
+    r4 = json.loads((P / "bench_r01_replicas4_mi355xhost.json").read_text())
+    pb = json.loads((P / "pathbench_r01_mi355xhost.json").read_text())
+    ref = json.loads((P / "baseline_r01_mi355xhost_reference.json").read_text())["results"]
+    cref = json.loads((P / "baseline_r01_container_reference.json").read_text())["results"]
+    lo = min(ref[k]["delivered_lines_per_s"] for k in ("config2", "config3", "config4"))
+    hi = max(ref[k]["delivered_lines_per_s"] for k in ("config2", "config3", "config4"))
+    clo = min(cref[k]["delivered_lines_per_s"] for k in ("config2", "config3", "config4"))
+    chi = max(cref[k]["delivered_lines_per_s"] for k in ("config2", "config3", "config4"))
+    body = f"""## 2. Formal CPU baseline (round 1) — the deliverable
+
+Status: **recorded**. Harness, rules and definitions: `DESIGN.md` §5–§6; raw JSON per run under `profiles/`
+(`baseline_r01_*`; this section is generated from them by `tools/refresh_baseline_md.py`). Every run below delivered
+*exactly* the expected number of lines to *every* client (`Delivered = expected ✓`). The talker is single-threaded:
+all server numbers are one core by construction.
+
+Columns: **Delivered lines/s** = lines written to recipients other than the sender ÷ timed wall (the BASELINE.json
+metric); **Server CPU µs/line** = talker CPU (`/proc/<pid>/schedstat`) ÷ every line it wrote, acks included, with the
+user-space share from `/proc/<pid>/stat` (10 ms ticks, coarse — `oracle/pathbench` gives the precise figure below);
+**Busy** = talker CPU ÷ wall (1.00 = the talker, not the load generator, is the bottleneck); **B/line** = bytes on the
+wire per written line. `config2_all_send` = all ten clients send concurrently (saturating variant of #2);
+`*_colour_on` = every account has colour on (two `write(2)` per recipient, `nuts333.c:1363,1365`).
+The synthetic clients run on 4 cores next to the talker's (`profiles/sweep_loadgen_threads_r01_mi355xhost.log`:
+2–7 receiver threads measure the same; spreading receivers over 10+ cores / a second CCD inflates the *talker's*
+write cost by ≈45 % through cache-line migration, an artefact of loopback).
+
+### 2.1 On the MI355X box's host cores
+
+{table('baseline_r01_mi355xhost_reference.md')}
+
+Same host, reference compiled **without** optimisation (what the reference's own `build` script produces):
+
+{table('baseline_r01_mi355xhost_reference_O0.md')}
+
+Same host, our CPU restatement (`oracle/talker_port`, parity-pinned; `cpu_baseline.kind = "port"`):
+
+{table('baseline_r01_mi355xhost_port.md')}
+
+`bench.py` (BASELINE `configs[1]`, 10 × 2000 lines) on that host: **{b['value']:,.0f} delivered lines/s**,
+{b['server_cpu_us_per_written_line']} µs of server CPU per written line, host-syscall roofline fraction **{b['roofline']['frac']}**
+(peak {b['roofline']['peak']:,.0f} write(2)/s/core from the closed-loop probe); config #4 shape: {b4['value']:,.0f} lines/s, fraction {b4['roofline']['frac']}.
+Independent replicas (`--gpus N`, no GPU involved): N=2 → {r2['value']:,.0f}, N=4 → {r4['value']:,.0f} lines/s.
+User-space work per recipient, timed in isolation (`oracle/pathbench`): transduce one 67-byte line {pb['transduce_say_colour_off_ns']} ns
+(shout, colour on: {pb['transduce_shout_colour_on_ns']} ns), fan-out predicate {pb['fanout_predicate_ns']} ns, format the line once {pb['format_line_once_ns']} ns.
+What touching the GPU costs there: {b['device_floor']['kernel_launch_plus_sync_us']} µs for one trivial kernel launch + sync,
+{b['device_floor']['h2d_64B_kernel_d2h_69KB_sync_us']} µs for a 64 B → kernel → 69 KB round trip (`profiles/rocprof_r01_kernel_stats.md`).
+
+### 2.2 In the build container (8 vCPU Xeon @ 2.1 GHz, KVM guest)
+
+{table('baseline_r01_container_reference.md')}
+
+`-O0` reference build:
+
+{table('baseline_r01_container_reference_O0.md')}
+
+Restatement:
+
+{table('baseline_r01_container_port.md')}
+
+### 2.3 Reading
+
+* Single talker, any N from 10 to 1000: **≈{lo / 1000:.0f}–{hi / 1000:.0f} k delivered lines/s on one EPYC 9575F core**,
+  {min(ref[k]['server_cpu_us_per_written_line'] for k in ('config2', 'config3', 'config4')):.2f}–{max(ref[k]['server_cpu_us_per_written_line'] for k in ('config2', 'config3', 'config4')):.2f} µs of CPU per written line, of which ≈{pb['transduce_say_colour_off_ns'] / 1000:.2f} µs is the
+  transducer; ≈{clo / 1000:.0f}–{chi / 1000:.0f} k lines/s and ≈5–7 µs in the (virtualised) build container, where the loopback TCP
+  path itself costs ≈5 µs per closed-loop write.
+* The talker already runs at ≈{b['roofline']['frac']:.2f} of what one core can do issuing nothing but `write(2)`.
+* Optimisation level barely matters (`-O0` vs `-O2` within noise): the time is not in user space.
+* Colour on costs ≈25 % (a second 4-byte `write` per recipient).
+* Config #5 (netlink): ≈75–100 input lines/s end to end, p99 ack 44–60 ms — the talker↔talker socket never sets
+  `TCP_NODELAY`, so consecutive small frames wait for a delayed ACK. 2000 input lines → 20,000 `MSG…EMSG` frames
+  talker2→talker1, 1000 `ACT` frames the other way, plus one `PRM` per `ACT`.
+* The survey-time figures in §3 below (≈2.3 µs/line with a Python driver) are consistent with the container numbers.
+"""
+    path = REPO / "BASELINE.md"
+    text = path.read_text()
+    if "<!-- FORMAL:BEGIN -->" not in text:
+        text = re.sub(r"## 2\. Formal CPU baseline.*?(?=## 3\. Survey-time)", "<!-- FORMAL:BEGIN -->\n<!-- FORMAL:END -->\n\n", text, flags=re.S)
+    text = re.sub(r"<!-- FORMAL:BEGIN -->.*?<!-- FORMAL:END -->", "<!-- FORMAL:BEGIN -->\n" + body + "<!-- FORMAL:END -->", text, flags=re.S)
+    path.write_text(text)
+
+
+if __name__ == "__main__":
+    main()
