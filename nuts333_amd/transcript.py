@@ -216,13 +216,16 @@ class Session:
     def _collect(self, actor: Client | None, first: bytes = b"") -> dict[str, bytes]:
         recv: dict[str, bytes] = {}
         order = ([actor] if actor else []) + [c for c in self.clients.values() if c is not actor]
+        # clients that can do the round trip go first: once any of them has its reply the talker
+        # (single-threaded) has finished the step, so whatever it wrote to the clients that cannot
+        # sync (AFK, away over a link, still logging in) is already queued and a plain drain gets it
         for c in order:
-            pre = first if c is actor else b""
             if c.logged_in and c.can_sync:
-                recv[c.key] = pre + self._sync(c)
-            else:
-                recv[c.key] = pre + self._drain_nowait(c)
-        return recv
+                recv[c.key] = (first if c is actor else b"") + self._sync(c)
+        for c in order:
+            if not (c.logged_in and c.can_sync):
+                recv[c.key] = (first if c is actor else b"") + self._drain_nowait(c)
+        return {c.key: recv[c.key] for c in order}
 
     @staticmethod
     def _drain_nowait(c: Client) -> bytes:

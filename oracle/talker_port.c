@@ -75,6 +75,8 @@ struct user {
     int type, port, site_port, login, sock, attempts, buffpos;
     int vis, ignall, ignshout, igntell, prompt, command_mode, muzzled, charmode_echo, colour, level;
     int remote_com;
+    int afk;                  /* 0, 1 = any input resets, 2 = locked until the password is typed */
+    char afk_mesg[61];
     time_t last_input, last_login, total_login, read_mail;
     int last_login_len;
     struct netlink *netlink, *pot_netlink;
@@ -539,8 +541,9 @@ static void look(struct user *u)
         struct user *o = users[i];
         if (o->room != u->room || o == u || (!o->vis && o->level > u->level)) continue;
         if (!seen++) write_user(u, "~FTYou can see:\n");
-        if (!o->vis) snprintf(text, sizeof(text), "     ~FR*~RS%s %s~RS  %s\n", o->name, o->desc, "");
-        else snprintf(text, sizeof(text), "      %s %s~RS  %s\n", o->name, o->desc, "");
+        const char *afk = o->afk ? "~BR(AFK)" : "";
+        if (!o->vis) snprintf(text, sizeof(text), "     ~FR*~RS%s %s~RS  %s\n", o->name, o->desc, afk);
+        else snprintf(text, sizeof(text), "      %s %s~RS  %s\n", o->name, o->desc, afk);
         write_user(u, text);
     }
     if (!seen) write_user(u, "~FTYou are all alone here.\n");
@@ -659,6 +662,11 @@ static void shout(struct user *u, const char *inpstr)
 /* shared early-outs of tell and pemote, nuts333.c:4149-4172 / 4251-4273 */
 static int private_blocked(struct user *u, struct user *t, const char *what)
 {
+    if (t->afk) {
+        if (t->afk_mesg[0]) snprintf(text, sizeof(text), "%s is AFK, message is: %s\n", t->name, t->afk_mesg);
+        else snprintf(text, sizeof(text), "%s is AFK at the moment.\n", t->name);
+        write_user(u, text); return 1;
+    }
     if (t->ignall && (u->level < NP_WIZ || t->level > u->level)) {
         snprintf(text, sizeof(text), "%s is ignoring everyone at the moment.\n", t->name); write_user(u, text); return 1;
     }
@@ -774,6 +782,67 @@ static void revtell(struct user *u)
     write_user(u, cnt ? "\n~BB~FG*** End ***\n\n" : "Revtell buffer is empty.\n");
 }
 
+/* nuts333.c:4772-4788: heard even by users who ignore everything (force_listen) */
+static void bcast(struct user *u, const char *inpstr)
+{
+    if (word_count < 2) { write_user(u, "Usage: bcast <message>\n"); return; }
+    if (u->muzzled) { write_user(u, "You are muzzled, you cannot broadcast anything.\n"); return; }
+    force_listen = 1;
+    if (u->vis) snprintf(text, sizeof(text), "\07\n~BR*** Broadcast message from %s ***\n%s\n\n", u->name, inpstr);
+    else snprintf(text, sizeof(text), "\07\n~BR*** Broadcast message ***\n%s\n\n", inpstr);
+    write_room(-1, text);
+}
+
+/* nuts333.c:6527-6565 */
+static void wizshout(struct user *u, const char *inpstr)
+{
+    if (u->muzzled) { write_user(u, "You are muzzled, you cannot wizshout.\n"); return; }
+    if (word_count < 2) { write_user(u, "Usage: wizshout [<superuser level>] <message>\n"); return; }
+    if (ban_swearing && np_contains_swearing(inpstr)) { write_user(u, "Swearing is not allowed here.\n"); return; }
+    for (char *p = word[1]; *p; p++) *p = (char)toupper((unsigned char)*p);
+    int lev = get_level(word[1]);
+    if (lev == -1) {
+        snprintf(text, sizeof(text), "~OLYou wizshout:~RS %s\n", inpstr); write_user(u, text);
+        snprintf(text, sizeof(text), "~OL%s wizshouts:~RS %s\n", u->name, inpstr);
+        write_level(NP_WIZ, 1, text, u);
+        return;
+    }
+    if (lev < NP_WIZ || word_count < 3) { write_user(u, "Usage: wizshout [<superuser level>] <message>\n"); return; }
+    if (lev > u->level) { write_user(u, "You cannot specifically shout to users of a higher level than yourself.\n"); return; }
+    inpstr = np_remove_first(inpstr);
+    snprintf(text, sizeof(text), "~OLYou wizshout to level %s:~RS %s\n", level_name[lev], inpstr); write_user(u, text);
+    snprintf(text, sizeof(text), "~OL%s wizshouts to level %s:~RS %s\n", u->name, level_name[lev], inpstr);
+    write_level(lev, 1, text, u);
+}
+
+/* nuts333.c:7409-7454 */
+static void afk(struct user *u, const char *inpstr)
+{
+    if (word_count > 1) {
+        int lock = !strcmp(word[1], "lock");
+        if (lock) {
+            if (u->type == T_REMOTE) { write_user(u, "Sorry, due to software limitations remote users cannot use the lock option.\n"); return; }
+            inpstr = np_remove_first(inpstr);
+        }
+        if (strlen(inpstr) > 60) { write_user(u, "AFK message too long.\n"); return; }
+        write_user(u, lock ? "You are now AFK with the session locked, enter your password to unlock it.\n"
+                           : "You are now AFK, press <return> to reset.\n");
+        if (inpstr[0]) { strcpy(u->afk_mesg, inpstr); write_user(u, "AFK message set.\n"); }
+        u->afk = lock ? 2 : 1;
+    } else {
+        write_user(u, "You are now AFK, press <return> to reset.\n");
+        u->afk = 1;
+    }
+    if (u->vis) {
+        if (u->afk_mesg[0]) snprintf(text, sizeof(text), "%s goes AFK: %s\n", u->name, u->afk_mesg);
+        else snprintf(text, sizeof(text), "%s goes AFK...\n", u->name);
+        write_room_except(u->room, text, u);
+    }
+}
+
+/* nuts333.c:2636-2642 */
+static void cls(struct user *u) { for (int i = 0; i < 5; i++) write_user(u, "\n\n\n\n\n\n\n\n\n\n"); }
+
 /* nuts333.c:6434-6456 */
 static void visibility(struct user *u, int vis)
 {
@@ -877,6 +946,10 @@ static void exec_com(struct user *u, char *inpstr)
                                  : "You are now ignoring tells and private emotes.\n");
         u->igntell = !u->igntell; break;
     case NP_REVTELL: revtell(u); break;
+    case NP_BCAST: bcast(u, inpstr); break;
+    case NP_WIZSHOUT: wizshout(u, inpstr); break;
+    case NP_AFK: afk(u, inpstr); break;
+    case NP_CLS: cls(u); break;
     default:
         snprintf(text, sizeof(text), "[talker_port] '%s' is outside the restated path.\n", np_command_name(com_num));
         write_user(u, text);
@@ -935,6 +1008,19 @@ static void user_input(struct user *u)
 
     for (int w = 0; w < NP_MAX_WORDS; w++) word[w][0] = 0;
     word_count = np_wordfind(inpstr, word);
+    if (u->afk) {
+        if (u->afk == 2) {
+            if (!word_count) { if (u->command_mode) prompt(u); return; }
+            const char *h = crypt(word[0], "NU");
+            if (!h || strcmp(h, u->pass)) { write_user(u, "Incorrect password.\n"); prompt(u); return; }
+            cls(u);
+            write_user(u, "Session unlocked, you are no longer AFK.\n");
+        } else write_user(u, "You are no longer AFK.\n");
+        u->afk_mesg[0] = 0;
+        if (u->vis) { snprintf(text, sizeof(text), "%s comes back from being AFK.\n", u->name); write_room_except(u->room, text, u); }
+        if (u->afk == 2) { u->afk = 0; prompt(u); return; }
+        u->afk = 0;
+    }
     if (!word_count) {
         if (u->room < 0) { snprintf(text, sizeof(text), "ACT %s NL\n", u->name); write_sock(u->netlink->sock, text); }
         if (u->command_mode) prompt(u);

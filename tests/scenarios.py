@@ -14,6 +14,8 @@ What they pin, by reference function:
   framing       terminate, char-mode assembly, pipelining drop, "." repeat      c:136-175, 369-411
   review        record / record_tell ring buffers                               c:2062-2082
   prompt        prompt() in speech and command mode                             c:2174-2197
+  afk_bcast     the AFK branch of the main loop (incl. locked sessions), bcast (force_listen),  c:180-203, 4772-4788, 6527-6565,
+                wizshout (write_level), cls                                              7409-7454, 2636-2642
   rooms         go / move_user / look: adjacency, prefix names, teleport, private     c:3942-4004, 4305-4459, 2412-2421
                 rooms, invisible movement
   login_paths   accept + 3-stage login incl. every error exit, new account, wizport,   c:263-311, 1451-1606, 1645-1673
@@ -278,6 +280,44 @@ def prompts():
     return {}, accounts, script
 
 
+def afk_bcast():
+    """The AFK branch of the main loop, and the two level-scoped fan-outs (nuts333.c:180-203, 4149-4155,
+    4772-4788, 6527-6565, 7409-7454)."""
+    accounts = [_acc(A), _acc(B), _acc(C, level=2), _acc(D, level=3)]
+
+    def script(s):
+        for k, n in (("a", A), ("b", B), ("c", C), ("d", D)):
+            s.connect(k); s.login(k, n)
+        s.line("a", ".afk", can_sync=False)
+        s.line("b", ".tell alice are you there")
+        s.line("b", "< alice pokes")
+        s.line("b", ".look")
+        s.line("b", "alice still hears the room")
+        s.line("a", "typing anything comes back first", can_sync=True)
+        s.line("a", ".afk back in five", can_sync=False)
+        s.line("b", ".tell alice hello?")
+        s.line("a", "", can_sync=True, note="an empty line is enough")
+        s.line("a", ".afk lock gone fishing", can_sync=False)
+        s.line("a", "wrongpassword", expect=b"Incorrect password.\n\r")
+        s.line("a", "test", expect=b"no longer AFK.\n\r", can_sync=True, note="cls, then unlocked")
+        s.line("a", ".afk " + "x" * 61)
+        s.line("c", ".wizshout for the wizzes")
+        s.line("c", ".wizshout ARCH too high for me")
+        s.line("d", ".wizshout wiz to WIZ and above")
+        s.line("d", ".wizshout arch to ARCH only")
+        s.line("d", ".wizshout user levels below WIZ are refused")
+        s.line("d", ".wizshout")
+        s.line("b", ".wizshout not for mortals")
+        s.line("b", ".ignall")
+        s.line("c", ".bcast everybody hears this, even those ignoring")
+        s.line("d", ".invis")
+        s.line("d", ".bcast anonymous")
+        s.line("a", ".bcast")
+        s.line("a", ".cls")
+
+    return {}, accounts, script
+
+
 def rooms():
     """go / move_user / look and who hears what while people move (nuts333.c:3942-4004, 4305-4459)."""
     accounts = [_acc(A), _acc(B, level=2), _acc(C, level=3), _acc(D, in_phrase="bounces in", out_phrase="rolls out")]
@@ -537,6 +577,7 @@ SCENARIOS = {
     "framing": framing,
     "review": review,
     "prompts": prompts,
+    "afk_bcast": afk_bcast,
     "rooms": rooms,
     "login_paths": login_paths,
     "capacity": capacity,

@@ -54,7 +54,7 @@ def test_load_generator_is_clean_under_asan_ubsan(asan_talker, asan_loadgen, mon
 
 
 # ---------------------------------------------------------------- the reference itself, under ASan
-SINGLE_TALKER = ["speech_colour_off", "speech_colour_mixed", "markup", "filters", "errors", "swearing", "framing",
+SINGLE_TALKER = ["afk_bcast", "speech_colour_off", "speech_colour_mixed", "markup", "filters", "errors", "swearing", "framing",
                  "review", "prompts", "rooms", "login_paths", "capacity", "netlink_wire_dial"]
 
 
