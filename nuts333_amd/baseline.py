@@ -90,7 +90,7 @@ def to_markdown(doc: dict) -> str:
 
 def main(argv: list[str] | None = None) -> int:
     ap = argparse.ArgumentParser()
-    ap.add_argument("--binary", default="auto", choices=["auto", "reference", "reference_O0", "port"])
+    ap.add_argument("--binary", default="auto", choices=["auto", "reference", "reference_O0", "port", "port_fast"])
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--out", default="")
     ap.add_argument("--quick", action="store_true", help="one tenth of the lines, 250 instead of 1000 clients")

@@ -61,6 +61,13 @@ def host_cpus() -> list[int]:
 
 def pick_binary(kind: str = "auto") -> tuple[Path, str]:
     """('reference' | 'port' | 'auto') -> (binary path, kind actually used)."""
+    if kind == "port_fast":
+        # the restatement with INTEGRATION.md section 3's CPU-side changes switched on (same bytes on the wire)
+        os.environ["NUTS_PORT_FAST"] = "1"
+        if not PORT_BINARY.exists():
+            raise FileNotFoundError("oracle/_build/talker_port is not built")
+        return PORT_BINARY, "port_fast"
+    os.environ.pop("NUTS_PORT_FAST", None)
     if kind in ("reference", "auto") and REF_BINARY.exists():
         return REF_BINARY, "reference"
     if kind == "reference":

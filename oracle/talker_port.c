@@ -28,6 +28,7 @@
 #include <fcntl.h>
 #include <netdb.h>
 #include <netinet/in.h>
+#include <netinet/tcp.h>
 #include <signal.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -110,6 +111,13 @@ static int gatecrash_level = NP_GOD + 1, wizport_level = NP_WIZ, minlogin_level 
 static int rem_user_maxlevel = NP_USER, rem_user_deflevel = NP_USER;
 static int thour, tmin;
 
+/* NUTS_PORT_FAST=1: the three CPU-side changes INTEGRATION.md section 3 proposes, so that their effect
+ * can be MEASURED instead of estimated.  Same bytes on every socket (the parity tests run in both
+ * modes); different work: (1) a broadcast is transduced once per colour variant, not once per
+ * recipient; (2) the trailing colour reset travels in the same write(2) as the line; (3) netlink
+ * sockets get TCP_NODELAY.  Off by default: the default build restates the reference's cost model. */
+static int fast_mode;
+
 static const char *level_name[] = { "NEW", "USER", "WIZ", "ARCH", "GOD" };
 static const char *invisname = "A presence";
 
@@ -191,6 +199,11 @@ static void write_user(struct user *u, const char *str)
         return;
     }
     int sock = u->sock;
+    if (fast_mode) {
+        char out[NP_TEXT_SIZE * 6 + 64];
+        size_t n = np_transduce(str, u->colour, out, sizeof(out));
+        if (n && n <= sizeof(out)) { if (write(sock, out, n) < 0) {} return; }
+    }
     np_write_user_stream(str, u->colour, emit_to_sock, &sock);
 }
 
@@ -207,6 +220,22 @@ static void write_level(int level, int above, const char *str, struct user *exce
 /* nuts333.c:1401-1429 (clone branch out of scope) */
 static void write_room_except(int rm, const char *str, struct user *except)
 {
+    if (fast_mode) {
+        /* the transducer's output depends only on the recipient's colour bit: two variants, built lazily */
+        static char variant[2][NP_TEXT_SIZE * 6 + 64];
+        size_t len[2] = { 0, 0 }; int have[2] = { 0, 0 };
+        for (int i = 0; i < nusers; i++) {
+            struct user *u = users[i];
+            struct np_listener l = { u->login, u->room >= 0, u->room == rm, u->ignall, u->ignshout, u == except };
+            if (!np_fanout_admits(&l, rm < 0, force_listen, com_num)) continue;
+            if (u->type == T_REMOTE) { write_user(u, str); continue; }
+            int c = u->colour ? 1 : 0;
+            if (!have[c]) { len[c] = np_transduce(str, c, variant[c], sizeof(variant[c])); have[c] = 1; }
+            if (len[c] && len[c] <= sizeof(variant[c])) { if (write(u->sock, variant[c], len[c]) < 0) {} }
+            else write_user(u, str);
+        }
+        return;
+    }
     for (int i = 0; i < nusers; i++) {
         struct user *u = users[i];
         struct np_listener l = { u->login, u->room >= 0, u->room == rm, u->ignall, u->ignshout, u == except };
@@ -1201,6 +1230,7 @@ static void init_sockets(void)
 int main(int argc, char **argv)
 {
     if (argc > 1) snprintf(confile, sizeof(confile), "%s", argv[1]);
+    fast_mode = getenv("NUTS_PORT_FAST") && getenv("NUTS_PORT_FAST")[0] == '1';
     printf("\n*** NUTS %s path restatement (talker_port) booting ***\n\n", VERSION);
     write_syslog("\n*** SERVER BOOTING ***\n", 0);
     signal(SIGPIPE, SIG_IGN);

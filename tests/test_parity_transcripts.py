@@ -50,6 +50,16 @@ def test_port_matches_golden(name, port_binary):
     assert got.get("files") == gold.get("files")
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_port_fast_mode_puts_the_same_bytes_on_the_wire(name, port_binary, monkeypatch):
+    """NUTS_PORT_FAST=1 (transduce once per colour variant, reset merged into the same write, TCP_NODELAY on
+    netlinks -- INTEGRATION.md section 3) must be invisible to every client and to a netlink peer."""
+    monkeypatch.setenv("NUTS_PORT_FAST", "1")
+    gold = _load(name)
+    got = run_scenario(name, port_binary)
+    assert got["steps"] == gold["steps"], _diff(gold["steps"], got["steps"])
+
+
 @pytest.mark.reference
 @pytest.mark.parametrize("name", NAMES)
 def test_reference_still_matches_golden(name, ref_binary):
