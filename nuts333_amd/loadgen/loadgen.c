@@ -477,7 +477,7 @@ static void *worker_main(void *arg) {
 }
 
 /* ------------------------------------------------------------------ /proc sampling */
-struct cpu_sample { double utime_s, stime_s; uint64_t sched_ns; };
+struct cpu_sample { double utime_s, stime_s; uint64_t sched_ns, syscr, syscw, wchar; };
 
 static void sample_pid(int pid, struct cpu_sample *s) {
     char path[64], buf[1024]; memset(s, 0, sizeof(*s));
@@ -497,6 +497,18 @@ static void sample_pid(int pid, struct cpu_sample *s) {
     snprintf(path, sizeof(path), "/proc/%d/schedstat", pid);
     fp = fopen(path, "r");
     if (fp) { unsigned long long ns = 0; if (fscanf(fp, "%llu", &ns) == 1) s->sched_ns = ns; fclose(fp); }
+    /* exact read/write system-call counts of the talker: /proc/<pid>/io (same uid) */
+    snprintf(path, sizeof(path), "/proc/%d/io", pid);
+    fp = fopen(path, "r");
+    if (fp) {
+        char key[32]; unsigned long long v;
+        while (fscanf(fp, "%31s %llu", key, &v) == 2) {
+            if (!strcmp(key, "syscr:")) s->syscr = v;
+            else if (!strcmp(key, "syscw:")) s->syscw = v;
+            else if (!strcmp(key, "wchar:")) s->wchar = v;
+        }
+        fclose(fp);
+    }
 }
 
 static int cmp_u64(const void *a, const void *b) {
@@ -728,9 +740,12 @@ int main(int argc, char **argv) {
            nlat ? (double)lat[(size_t)((double)(nlat - 1) * 0.99)] / 1e3 : 0.0, nlat ? (double)lat[nlat - 1] / 1e3 : 0.0);
     printf("\"servers\":[");
     for (int i = 0; i < g_nservers; i++) {
-        printf("%s{\"pid\":%d,\"utime_s\":%.3f,\"stime_s\":%.3f,\"cpu_ns\":%llu}", i ? "," : "", g_server_pids[i],
+        printf("%s{\"pid\":%d,\"utime_s\":%.3f,\"stime_s\":%.3f,\"cpu_ns\":%llu,\"read_syscalls\":%llu,\"write_syscalls\":%llu,\"bytes_written\":%llu}",
+               i ? "," : "", g_server_pids[i],
                failed ? 0.0 : s1[i].utime_s - s0[i].utime_s, failed ? 0.0 : s1[i].stime_s - s0[i].stime_s,
-               failed ? 0ull : (unsigned long long)(s1[i].sched_ns - s0[i].sched_ns));
+               failed ? 0ull : (unsigned long long)(s1[i].sched_ns - s0[i].sched_ns),
+               (unsigned long long)(s1[i].syscr - s0[i].syscr), (unsigned long long)(s1[i].syscw - s0[i].syscw),
+               (unsigned long long)(s1[i].wchar - s0[i].wchar));
     }
     printf("],\"per_client_lines\":[");
     for (int i = 0; i < g_nclients; i++) printf("%s%llu", i ? "," : "", (unsigned long long)g_clients[i].rx_lines);

@@ -173,6 +173,8 @@ def summarise(res: dict) -> dict:
         tot = s["utime_s"] + s["stime_s"]
         s["user_frac"] = s["utime_s"] / tot if tot > 0 else None
         s["busy_frac"] = s["cpu_ns"] / 1e9 / wall if wall > 0 else 0.0
+        s["write_syscalls_per_line"] = s.get("write_syscalls", 0) / written if written else 0.0
+        s["read_syscalls_per_input_line"] = s.get("read_syscalls", 0) / res["input_lines"] if res["input_lines"] else 0.0
     return res
 
 

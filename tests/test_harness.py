@@ -129,6 +129,38 @@ def test_config5_two_talkers_over_a_netlink(port_binary):
     assert res["netlink_frames_t2_to_t1"] == 300
 
 
+def _syscalls(res):
+    s = res["servers"][0]
+    return s["read_syscalls"], s["write_syscalls"], s["bytes_written"]
+
+
+def test_syscall_cost_model_of_the_restatement(port_binary, monkeypatch):
+    """Exact counts from /proc/<pid>/io: one read(2) per input line, one write(2) per written line, two
+    with colour on (nuts333.c:136, 1363, 1365); the fast mode folds the reset into the same write."""
+    monkeypatch.delenv("NUTS_PORT_FAST", raising=False)
+    off = workloads.config2(lines=400, binary=port_binary)
+    on = workloads.config2(lines=400, colour=1, binary=port_binary)
+    assert _syscalls(off) == (400, 4000, off["bytes_total"]) and _syscalls(on) == (400, 8000, on["bytes_total"])
+    monkeypatch.setenv("NUTS_PORT_FAST", "1")
+    fast = workloads.config2(lines=400, colour=1, binary=port_binary)
+    assert _syscalls(fast) == (400, 4000, on["bytes_total"]) and fast["exact"]
+
+
+@pytest.mark.reference
+def test_restatement_issues_the_same_system_calls_as_the_reference(ref_binary, port_binary, monkeypatch):
+    """The restatement stands in as cpu_baseline kind "port": it must cost what the reference costs.
+    Same workload, same number of read(2)/write(2) calls, same bytes -- colour off and on, N = 10 and 200."""
+    monkeypatch.delenv("NUTS_PORT_FAST", raising=False)
+    for kw in ({"lines": 400}, {"lines": 400, "colour": 1}):
+        assert _syscalls(workloads.config2(binary=ref_binary, **kw)) == _syscalls(workloads.config2(binary=port_binary, **kw))
+    a = workloads.config4(lines=30, n=200, binary=ref_binary)
+    b = workloads.config4(lines=30, n=200, binary=port_binary)
+    assert _syscalls(a) == _syscalls(b) == (30, 30 * 200, a["bytes_total"])
+    c = workloads.config3(per_client=10, n=25, binary=ref_binary)
+    d = workloads.config3(per_client=10, n=25, binary=port_binary)
+    assert _syscalls(c) == _syscalls(d)
+
+
 @pytest.mark.reference
 def test_small_workloads_against_the_reference(ref_binary):
     _check(workloads.config2(lines=300, warmup=30, binary=ref_binary), "config2")
