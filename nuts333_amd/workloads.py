@@ -151,9 +151,9 @@ def run_spec(spec: Spec, talkers: Sequence[Talker], *, timeout_s: float = 600.0,
     try:
         res = json.loads(proc.stdout.decode().strip().splitlines()[-1])
     except (IndexError, json.JSONDecodeError):
-        raise RuntimeError(f"loadgen produced no result (rc={proc.returncode}): {proc.stderr.decode()[-2000:]}")
+        raise RuntimeError(f"loadgen produced no result (rc={proc.returncode}): {proc.stderr.decode(errors="replace")[-2000:]}")
     if proc.returncode != 0 or not res.get("ok"):
-        raise RuntimeError(f"loadgen failed (rc={proc.returncode}): {proc.stderr.decode()[-2000:]} {res}")
+        raise RuntimeError(f"loadgen failed (rc={proc.returncode}): {proc.stderr.decode(errors="replace")[-2000:]} {res}")
     res["expected_deliveries"] = spec.expected_deliveries
     res["per_client_exact"] = res.pop("per_client_lines") == spec.expected_per_client
     res["exact"] = bool(res["per_client_exact"] and res["lines_total"] == spec.expect_lines
