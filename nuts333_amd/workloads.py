@@ -148,12 +148,13 @@ def run_spec(spec: Spec, talkers: Sequence[Talker], *, timeout_s: float = 600.0,
     text = spec.render([t.pid for t in talkers], threads, client_cpus, timeout_s, login_window, drain_quiet_ms=quiet)
     proc = subprocess.run([str(LOADGEN_BIN)], input=text.encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                           timeout=timeout_s + 60)
+    err = proc.stderr.decode(errors="replace")[-2000:]
     try:
         res = json.loads(proc.stdout.decode().strip().splitlines()[-1])
     except (IndexError, json.JSONDecodeError):
-        raise RuntimeError(f"loadgen produced no result (rc={proc.returncode}): {proc.stderr.decode(errors="replace")[-2000:]}")
+        raise RuntimeError(f"loadgen produced no result (rc={proc.returncode}): {err}")
     if proc.returncode != 0 or not res.get("ok"):
-        raise RuntimeError(f"loadgen failed (rc={proc.returncode}): {proc.stderr.decode(errors="replace")[-2000:]} {res}")
+        raise RuntimeError(f"loadgen failed (rc={proc.returncode}): {err} {res}")
     res["expected_deliveries"] = spec.expected_deliveries
     res["per_client_exact"] = res.pop("per_client_lines") == spec.expected_per_client
     res["exact"] = bool(res["per_client_exact"] and res["lines_total"] == spec.expect_lines
