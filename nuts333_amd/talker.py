@@ -66,12 +66,13 @@ def free_ports(n: int = 3) -> list[int]:
 
 class Talker:
     def __init__(self, binary: os.PathLike | str, root: os.PathLike | str, config_name: str = "config",
-                 cpu: int | None = None, tz: str = "UTC"):
+                 cpu: int | None = None, tz: str = "UTC", burn_fds: int = 0):
         self.binary = Path(binary)
         self.root = Path(root)
         self.config_name = config_name
         self.cpu = cpu
         self.tz = tz
+        self.burn_fds = burn_fds     # tests only: start the daemon with this many descriptors already in use
         self.pid: int | None = None
 
     # -- lifecycle -------------------------------------------------------------------
@@ -94,12 +95,15 @@ class Talker:
                 except OSError:
                     pass
 
+        burn = [os.open(os.devnull, os.O_RDONLY) for _ in range(self.burn_fds)]
         try:
             launcher = subprocess.Popen([self.binary.name[:30], self.config_name], executable=str(self.binary),
-                                        cwd=self.root, stdin=subprocess.DEVNULL,
+                                        cwd=self.root, stdin=subprocess.DEVNULL, pass_fds=burn,
                                         stdout=out, stderr=subprocess.STDOUT, env=env, preexec_fn=_pre)
         finally:
             out.close()
+            for fd in burn:
+                os.close(fd)
         deadline = time.monotonic() + timeout
         rc = None
         while time.monotonic() < deadline:

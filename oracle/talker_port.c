@@ -1088,6 +1088,13 @@ static void accept_connection(int lsock, int num)
     struct sockaddr_in addr; socklen_t sz = sizeof(addr);
     int s = accept(lsock, (struct sockaddr *)&addr, &sz);
     if (s < 0) return;
+    if (s >= FD_SETSIZE) {
+        /* Deliberate divergence: the reference has no such guard (nuts333.c:94,251-258,274) and, once
+           RLIMIT_NOFILE lets accept() hand out descriptor 1024, FD_SET() runs off the end of the mask: the
+           fortified -O2 build aborts ("buffer overflow detected"), the -O0 build corrupts its stack and
+           stops serving.  A test oracle must outlive its test, so we turn the connection away. */
+        write_sock(s, "\n\rSorry, the talker is full at the moment.\n\n\r"); close(s); return;
+    }
     if (num == 2) { accept_server_connection(s, addr); return; }
     char site[81]; snprintf(site, sizeof(site), "%s", site_of(addr));
     if (listed_in("siteban", site, 1)) { write_sock(s, "\n\rLogins from your site/domain are banned.\n\n\r"); close(s); return; }

@@ -71,6 +71,64 @@ def test_both_talkers_accept_the_generated_tree(tmp_path, port_binary):
         assert not t.alive()
 
 
+def test_restatement_survives_the_fd_setsize_cliff(tmp_path, port_binary):
+    """select() with FD_SETSIZE: the first descriptor >= 1024 cannot go into the mask.  The reference aborts there
+    (-O2, fortified FD_SET) or corrupts memory (-O0) -- INTEGRATION.md section 4; the restatement turns the client
+    away.  The daemon is started with 1000 descriptors already in use so that 40 connections reach the cliff."""
+    import resource
+    import socket
+    soft, _ = resource.getrlimit(resource.RLIMIT_NOFILE)
+    if soft < 1200:
+        pytest.skip("RLIMIT_NOFILE too low")
+    ports = free_ports(3)
+    root = pv.write_tree(tmp_path / "t", pv.TalkerConfig(mainport=ports[0], wizport=ports[1], linkport=ports[2], max_users=2000))
+    socks = []
+    with Talker(port_binary, root, burn_fds=1000) as t:
+        try:
+            for _ in range(40):
+                socks.append(socket.create_connection(("127.0.0.1", ports[0]), timeout=5))
+            socks[-1].settimeout(5)
+            data = b""
+            while b"talker is full" not in data:
+                chunk = socks[-1].recv(4096)
+                if not chunk:
+                    break
+                data += chunk
+            assert b"Sorry, the talker is full at the moment." in data
+            assert t.alive()
+        finally:
+            for s in socks:
+                s.close()
+
+
+@pytest.mark.reference
+def test_reference_dies_at_the_fd_setsize_cliff(tmp_path, ref_binary):
+    """Documents the defect (nuts333.c:94,251-258,274): the fortified -O2 build aborts on FD_SET(1024)."""
+    import resource
+    import socket
+    import time
+    if resource.getrlimit(resource.RLIMIT_NOFILE)[0] < 1200:
+        pytest.skip("RLIMIT_NOFILE too low")
+    ports = free_ports(3)
+    root = pv.write_tree(tmp_path / "t", pv.TalkerConfig(mainport=ports[0], wizport=ports[1], linkport=ports[2], max_users=2000))
+    socks = []
+    t = Talker(ref_binary, root, burn_fds=1000)
+    t.start()
+    try:
+        for _ in range(40):
+            try:
+                socks.append(socket.create_connection(("127.0.0.1", ports[0]), timeout=2))
+            except OSError:
+                break
+        time.sleep(0.3)
+        assert not t.alive()
+        assert b"buffer overflow detected" in (root / "boot.log").read_bytes()
+    finally:
+        for s in socks:
+            s.close()
+        t.stop()
+
+
 def test_boot_failure_is_reported(tmp_path, port_binary):
     root = pv.write_tree(tmp_path / "bad", pv.TalkerConfig())
     (root / "datafiles" / "config").write_text("INIT:\nlogging YES\n")      # the shipped config2's bad option (c:599-621)
