@@ -48,7 +48,7 @@
 #define MAX_NETLINKS 16
 
 enum { ACC_PUBLIC = 0, ACC_PRIVATE = 1, ACC_FIXED = 2, ACC_FIXED_PUBLIC = 2, ACC_FIXED_PRIVATE = 3 };  /* nuts333.h:45-49 */
-enum { T_LOCAL = 0, T_REMOTE = 2 };                                                                   /* nuts333.h:57-59 */
+enum { T_LOCAL = 0, T_CLONE = 1, T_REMOTE = 2 };                                                                   /* nuts333.h:57-59 */
 enum { NL_UNCONNECTED, NL_INCOMING, NL_OUTGOING };                                                      /* nuts333.h:112-114 */
 enum { ST_DOWN, ST_VERIFYING, ST_UP };
 enum { ALLOW_ALL, ALLOW_IN, ALLOW_OUT };
@@ -76,6 +76,8 @@ struct user {
     int type, port, site_port, login, sock, attempts, buffpos;
     int vis, ignall, ignshout, igntell, prompt, command_mode, muzzled, charmode_echo, colour, level;
     int remote_com;
+    struct user *owner;       /* clones: the user whose socket they report to (nuts333.c:7143-7147) */
+    int clone_hear;           /* 0 nothing, 1 swearing only, 2 everything (nuts333.h:60-62) */
     int afk;                  /* 0, 1 = any input resets, 2 = locked until the password is typed */
     char afk_mesg[61];
     time_t last_input, last_login, total_login, read_mail;
@@ -104,7 +106,7 @@ static int word_count, com_num, force_listen, no_prompt, destructed;
 
 static int port[3], listen_sock[3];
 static char verification[81], confile[64] = "config";
-static int max_users = 50, num_of_users, num_of_logins;
+static int max_users = 50, max_clones = 1, num_of_users, num_of_logins;
 static int ban_swearing, colour_def = 1, prompt_def, charecho_def, allow_caps_in_name = 1;
 static int system_logging = 1, password_echo, auto_connect = 1, min_private_users = 2;
 static int gatecrash_level = NP_GOD + 1, wizport_level = NP_WIZ, minlogin_level = -1;
@@ -171,8 +173,8 @@ static int get_room(const char *name)
 static struct user *get_user(char *name)
 {
     name[0] = (char)toupper((unsigned char)name[0]);
-    for (int i = 0; i < nusers; i++) { struct user *u = users[i]; if (!u->login && !strcmp(u->name, name)) return u; }
-    for (int i = 0; i < nusers; i++) { struct user *u = users[i]; if (!u->login && strstr(u->name, name)) return u; }
+    for (int i = 0; i < nusers; i++) { struct user *u = users[i]; if (!u->login && u->type != T_CLONE && !strcmp(u->name, name)) return u; }
+    for (int i = 0; i < nusers; i++) { struct user *u = users[i]; if (!u->login && u->type != T_CLONE && strstr(u->name, name)) return u; }
     return NULL;
 }
 
@@ -212,12 +214,25 @@ static void write_level(int level, int above, const char *str, struct user *exce
 {
     for (int i = 0; i < nusers; i++) {
         struct user *u = users[i];
-        if (u == except || u->login) continue;
+        if (u == except || u->login || u->type == T_CLONE) continue;
         if ((above && u->level >= level) || (!above && u->level <= level)) write_user(u, str);
     }
 }
 
-/* nuts333.c:1401-1429 (clone branch out of scope) */
+/* the clone branch of the fan-out, nuts333.c:1416-1426: a clone relays what is said in ITS room to its
+ * owner, prefixed with the room name; messages for every room (shouts, system lines) are skipped
+ * because the owner hears those anyway */
+static void clone_relay(struct user *u, int rm, const char *str)
+{
+    if (u->clone_hear == 0 || u->owner->ignall) return;
+    if (rm != u->room) return;
+    if (u->clone_hear == 1 && !np_contains_swearing(str)) return;
+    char text2[NP_TEXT_SIZE + 64];
+    snprintf(text2, sizeof(text2), "~FT[ %s ]:~RS %s", rooms[u->room].name, str);
+    write_user(u->owner, text2);
+}
+
+/* nuts333.c:1401-1429 */
 static void write_room_except(int rm, const char *str, struct user *except)
 {
     if (fast_mode) {
@@ -228,6 +243,7 @@ static void write_room_except(int rm, const char *str, struct user *except)
             struct user *u = users[i];
             struct np_listener l = { u->login, u->room >= 0, u->room == rm, u->ignall, u->ignshout, u == except };
             if (!np_fanout_admits(&l, rm < 0, force_listen, com_num)) continue;
+            if (u->type == T_CLONE) { clone_relay(u, rm, str); continue; }
             if (u->type == T_REMOTE) { write_user(u, str); continue; }
             int c = u->colour ? 1 : 0;
             if (!have[c]) { len[c] = np_transduce(str, c, variant[c], sizeof(variant[c])); have[c] = 1; }
@@ -239,7 +255,9 @@ static void write_room_except(int rm, const char *str, struct user *except)
     for (int i = 0; i < nusers; i++) {
         struct user *u = users[i];
         struct np_listener l = { u->login, u->room >= 0, u->room == rm, u->ignall, u->ignshout, u == except };
-        if (np_fanout_admits(&l, rm < 0, force_listen, com_num)) write_user(u, str);
+        if (!np_fanout_admits(&l, rm < 0, force_listen, com_num)) continue;
+        if (u->type == T_CLONE) clone_relay(u, rm, str);
+        else write_user(u, str);
     }
 }
 static void write_room(int rm, const char *str) { write_room_except(rm, str, NULL); }
@@ -286,6 +304,7 @@ static struct user *create_user(void)
     u->type = T_LOCAL; u->room = -1; u->invite_room = -1; u->sock = -1; u->vis = 1; u->remote_com = -1;
     u->read_mail = u->last_input = u->last_login = time(NULL);
     u->prompt = prompt_def; u->colour = colour_def; u->charmode_echo = charecho_def;
+    u->clone_hear = 2;
     return u;
 }
 
@@ -307,6 +326,21 @@ static int user_index(const struct user *u)
 {
     for (int i = 0; i < nusers; i++) if (users[i] == u) return i;
     return -1;
+}
+
+/* nuts333.c:2870-2882 */
+static void destroy_user_clones(struct user *owner)
+{
+    for (int i = 0; i < nusers;) {
+        struct user *u = users[i];
+        if (u->type == T_CLONE && u->owner == owner) {
+            snprintf(text, sizeof(text), "The clone of %s shimmers and vanishes.\n", u->name);
+            write_room_except(u->room, text, NULL);
+            destruct_user(u);
+            continue;
+        }
+        i++;
+    }
 }
 
 /* nuts333.c:2087-2107 */
@@ -527,6 +561,7 @@ static void disconnect_user(struct user *u)
         write_room_except(rm, text, u);
     }
     num_of_users--;
+    destroy_user_clones(u);
     destruct_user(u);
     reset_access(rm);
 }
@@ -631,6 +666,7 @@ static void go(struct user *u)
             snprintf(text, sizeof(text), "REMVD %s\n", u->name); write_sock(nl->sock, text);
             if (u->vis) { snprintf(text, sizeof(text), "%s goes to the %s\n", u->name, nl->service); write_room_except(rm, text, u); }
             else write_room_except(rm, "A presence leaves the room.\n", u);
+            destroy_user_clones(u);
             destruct_user(u); reset_access(rm); num_of_users--; no_prompt = 1;
             return;
         }
@@ -668,6 +704,12 @@ static void say(struct user *u, const char *inpstr)
     }
     if (word_count < 2 && u->command_mode) { write_user(u, "Say what?\n"); return; }
     const char *verb = np_say_verb(inpstr);
+    if (u->type == T_CLONE) {                                     /* c:4085-4090: no swear check, no "You say" */
+        snprintf(text, sizeof(text), "Clone of %s %ss: %s\n", u->name, verb, inpstr);
+        write_room(u->room, text);
+        np_record(&rooms[u->room].rev[0][0], NP_REVIEW_LINES, &rooms[u->room].revline, text);
+        return;
+    }
     if (ban_swearing && np_contains_swearing(inpstr)) { write_user(u, "Swearing is not allowed here.\n"); return; }
     snprintf(text, sizeof(text), "You %s: %s\n", verb, inpstr);
     write_user(u, text);
@@ -869,6 +911,122 @@ static void afk(struct user *u, const char *inpstr)
     }
 }
 
+/* ---- clones (nuts333.c:7100-7357): listener objects that share their owner's socket ---- */
+static struct user *find_clone(const struct user *owner, int rm)
+{
+    for (int i = 0; i < nusers; i++) if (users[i]->type == T_CLONE && users[i]->room == rm && users[i]->owner == owner) return users[i];
+    return NULL;
+}
+
+/* nuts333.c:7100-7162 */
+static void create_clone(struct user *u)
+{
+    int rm = u->room;
+    if (word_count >= 2 && (rm = get_room(word[1])) < 0) { write_user(u, "There is no such room.\n"); return; }
+    if (!has_room_access(u, rm)) { write_user(u, "That room is currently private, you cannot create a clone there.\n"); return; }
+    int cnt = 0;
+    for (int i = 0; i < nusers; i++) {
+        struct user *c = users[i];
+        if (c->type != T_CLONE || c->owner != u) continue;
+        if (c->room == rm) { snprintf(text, sizeof(text), "You already have a clone in the %s.\n", rooms[rm].name); write_user(u, text); return; }
+        if (++cnt == max_clones) { write_user(u, "You already have the maximum number of clones allowed.\n"); return; }
+    }
+    struct user *c = create_user();
+    if (!c) return;
+    c->type = T_CLONE; c->sock = u->sock; c->room = rm; c->owner = u;
+    strcpy(c->name, u->name); strcpy(c->desc, "~BR(CLONE)");
+    if (rm == u->room) write_user(u, "~FB~OLYou whisper a haunting spell and a clone is created here.\n");
+    else { snprintf(text, sizeof(text), "~FB~OLYou whisper a haunting spell and a clone is created in the %s.\n", rooms[rm].name); write_user(u, text); }
+    snprintf(text, sizeof(text), "~FB~OL%s whispers a haunting spell...\n", u->vis ? u->name : invisname);
+    write_room_except(u->room, text, u);
+    snprintf(text, sizeof(text), "~FB~OLA clone of %s appears in a swirling magical mist!\n", u->name);
+    write_room_except(rm, text, u);
+}
+
+/* nuts333.c:7166-7210 */
+static void destroy_clone(struct user *u)
+{
+    int rm = u->room;
+    struct user *whose = u;
+    if (word_count >= 2 && (rm = get_room(word[1])) < 0) { write_user(u, "There is no such room.\n"); return; }
+    if (word_count > 2) {
+        if (!(whose = get_user(word[2]))) { write_user(u, "There is no one of that name logged on.\n"); return; }
+        if (whose->level >= u->level) { write_user(u, "You cannot destroy the clone of a user of an equal or higher level.\n"); return; }
+    }
+    struct user *c = find_clone(whose, rm);
+    if (!c) {
+        if (whose == u) snprintf(text, sizeof(text), "You do not have a clone in the %s.\n", rooms[rm].name);
+        else snprintf(text, sizeof(text), "%s does not have a clone the %s.\n", whose->name, rooms[rm].name);
+        write_user(u, text); return;
+    }
+    destruct_user(c);
+    reset_access(rm);
+    write_user(u, "~FM~OLYou whisper a sharp spell and the clone is destroyed.\n");
+    snprintf(text, sizeof(text), "~FM~OL%s whispers a sharp spell...\n", u->vis ? u->name : invisname);
+    write_room_except(u->room, text, u);
+    snprintf(text, sizeof(text), "~FM~OLThe clone of %s shimmers and vanishes.\n", whose->name);
+    write_room(rm, text);
+    if (whose != u) { snprintf(text, sizeof(text), "~OLSYSTEM: ~FR%s has destroyed your clone in the %s.\n", u->name, rooms[rm].name); write_user(whose, text); }
+    destructed = 0;
+}
+
+/* nuts333.c:7214-7234 */
+static void myclones(struct user *u)
+{
+    int cnt = 0;
+    for (int i = 0; i < nusers; i++) {
+        struct user *c = users[i];
+        if (c->type != T_CLONE || c->owner != u) continue;
+        if (++cnt == 1) write_user(u, "\n~BB*** Rooms you have clones in ***\n\n");
+        snprintf(text, sizeof(text), "  %s\n", rooms[c->room].name); write_user(u, text);
+    }
+    if (!cnt) { write_user(u, "You have no clones.\n"); return; }
+    snprintf(text, sizeof(text), "\nTotal of %d clones.\n\n", cnt); write_user(u, text);
+}
+
+/* nuts333.c:7262-7291 */
+static void clone_switch(struct user *u)
+{
+    if (word_count < 2) { write_user(u, "Usage: switch <room clone is in>\n"); return; }
+    int rm = get_room(word[1]);
+    if (rm < 0) { write_user(u, "There is no such room.\n"); return; }
+    struct user *c = find_clone(u, rm);
+    if (!c) { write_user(u, "You do not have a clone in that room.\n"); return; }
+    write_user(u, "\n~FB~OLYou experience a strange sensation...\n");
+    c->room = u->room; u->room = rm;
+    snprintf(text, sizeof(text), "The clone of %s comes alive!\n", c->name); write_room_except(u->room, text, u);
+    snprintf(text, sizeof(text), "%s turns into a clone!\n", c->name); write_room_except(c->room, text, c);
+    look(u);
+}
+
+static void say(struct user *u, const char *inpstr);
+/* nuts333.c:7295-7320 */
+static void clone_say(struct user *u, const char *inpstr)
+{
+    if (u->muzzled) { write_user(u, "You are muzzled, your clone cannot speak.\n"); return; }
+    if (word_count < 3) { write_user(u, "Usage: csay <room clone is in> <message>\n"); return; }
+    int rm = get_room(word[1]);
+    if (rm < 0) { write_user(u, "There is no such room.\n"); return; }
+    struct user *c = find_clone(u, rm);
+    if (!c) { write_user(u, "You do not have a clone in that room.\n"); return; }
+    say(c, np_remove_first(inpstr));
+}
+
+/* nuts333.c:7325-7357 */
+static void clone_hear(struct user *u)
+{
+    if (word_count < 3 || (strcmp(word[2], "all") && strcmp(word[2], "swears") && strcmp(word[2], "nothing"))) {
+        write_user(u, "Usage: chear <room clone is in> all/swears/nothing\n"); return;
+    }
+    int rm = get_room(word[1]);
+    if (rm < 0) { write_user(u, "There is no such room.\n"); return; }
+    struct user *c = find_clone(u, rm);
+    if (!c) { write_user(u, "You do not have a clone in that room.\n"); return; }
+    if (!strcmp(word[2], "all")) { c->clone_hear = 2; write_user(u, "Clone will now hear everything.\n"); }
+    else if (!strcmp(word[2], "swears")) { c->clone_hear = 1; write_user(u, "Clone will now only hear swearing.\n"); }
+    else { c->clone_hear = 0; write_user(u, "Clone will now hear nothing.\n"); }
+}
+
 /* nuts333.c:2636-2642 */
 static void cls(struct user *u) { for (int i = 0; i < 5; i++) write_user(u, "\n\n\n\n\n\n\n\n\n\n"); }
 
@@ -979,6 +1137,12 @@ static void exec_com(struct user *u, char *inpstr)
     case NP_WIZSHOUT: wizshout(u, inpstr); break;
     case NP_AFK: afk(u, inpstr); break;
     case NP_CLS: cls(u); break;
+    case NP_CREATE: create_clone(u); break;
+    case NP_DESTROY: destroy_clone(u); break;
+    case NP_MYCLONES: myclones(u); break;
+    case NP_SWITCH: clone_switch(u); break;
+    case NP_CSAY: clone_say(u, inpstr); break;
+    case NP_CHEAR: clone_hear(u); break;
     default:
         snprintf(text, sizeof(text), "[talker_port] '%s' is outside the restated path.\n", np_command_name(com_num));
         write_user(u, text);
@@ -1147,6 +1311,7 @@ static void load_config(void)
             else if (!strcmp(w[0], "linkport")) port[2] = v;
             else if (!strcmp(w[0], "verification")) snprintf(verification, sizeof(verification), "%s", w[1]);
             else if (!strcmp(w[0], "max_users")) max_users = v;
+            else if (!strcmp(w[0], "max_clones")) max_clones = v;
             else if (!strcmp(w[0], "min_private")) min_private_users = v;
             else if (!strcmp(w[0], "system_logging")) r = system_logging = onoff(w[1]);
             else if (!strcmp(w[0], "colour_def")) r = colour_def = onoff(w[1]);
@@ -1164,7 +1329,7 @@ static void load_config(void)
             else {
                 /* accepted and ignored: they steer subsystems outside the path */
                 static const char *ignored[] = { "mesg_life", "ignore_mp_level", "mesg_check_time", "heartbeat", "login_idle_time",
-                    "user_idle_time", "ignore_sigterm", "max_clones", "crash_action", "time_out_afks", "time_out_maxlevel", NULL };
+                    "user_idle_time", "ignore_sigterm", "crash_action", "time_out_afks", "time_out_maxlevel", NULL };
                 int ok = 0;
                 for (int i = 0; ignored[i]; i++) ok |= !strcmp(ignored[i], w[0]);
                 if (!ok) boot_exit("unknown INIT option on line %d", lineno);

@@ -16,6 +16,8 @@ What they pin, by reference function:
   prompt        prompt() in speech and command mode                             c:2174-2197
   afk_bcast     the AFK branch of the main loop (incl. locked sessions), bcast (force_listen),  c:180-203, 4772-4788, 6527-6565,
                 wizshout (write_level), cls                                              7409-7454, 2636-2642
+  clones        the clone branch of write_room_except: relay to the owner, hear all/swears/      c:1416-1426, 4085-4090, 7100-7357,
+                nothing, csay, switch, destroy, clean-up at logout                        2870-2882
   rooms         go / move_user / look: adjacency, prefix names, teleport, private     c:3942-4004, 4305-4459, 2412-2421
                 rooms, invisible movement
   login_paths   accept + 3-stage login incl. every error exit, new account, wizport,   c:263-311, 1451-1606, 1645-1673
@@ -318,6 +320,53 @@ def afk_bcast():
     return {}, accounts, script
 
 
+def clones():
+    """The clone branch of the fan-out: a listener object in another room that relays to its owner
+    (nuts333.c:1416-1426, 4085-4090, 7100-7357, 2870-2882)."""
+    accounts = [_acc(A), _acc(B), _acc(D, level=3)]
+
+    def script(s):
+        for k, n in (("a", A), ("b", B), ("d", D)):
+            s.connect(k); s.login(k, n)
+        s.line("a", ".go hallway")
+        s.line("d", ".clone hallway")
+        s.line("a", ".look", note="the clone is listed like a user")
+        s.line("a", "said next to the clone")
+        s.line("a", ";emotes next to the clone")
+        s.line("a", ".shout shouts are not relayed: the owner hears them anyway")
+        s.line("b", "said in the drive, where the owner is")
+        s.line("d", ".clone hallway", note="one per room")
+        s.line("d", ".clone")
+        s.line("d", ".clone corridor", note="max_clones 2")
+        s.line("d", ".myclones")
+        s.line("d", ".chear hallway swears")
+        s.line("a", "a clean line is dropped")
+        s.line("a", "a shit line is relayed")
+        s.line("d", ".chear hallway nothing")
+        s.line("a", "nothing gets through")
+        s.line("d", ".chear hallway everything")
+        s.line("d", ".chear hallway all")
+        s.line("d", ".ignall")
+        s.line("a", "owner ignores everyone: no relay")
+        s.line("d", ".ignall")
+        s.line("d", ".csay hallway the clone speaks")
+        s.line("d", ".csay hallway does it ask?")
+        s.line("d", ".csay lounge no clone there")
+        s.line("a", ".review")
+        s.line("a", ".tell dave tells go to the owner, not the clone")
+        s.line("d", ".switch hallway")
+        s.line("a", "now dave himself is here")
+        s.line("b", "and the clone listens in the drive")
+        s.line("d", ".destroy drive")
+        s.line("d", ".destroy drive")
+        s.line("d", ".destroy hallway alice")
+        s.line("d", ".clone corridor")
+        s.close("d")
+        s.line("a", "the owner left, the clones went with him")
+
+    return {"max_clones": 2}, accounts, script
+
+
 def rooms():
     """go / move_user / look and who hears what while people move (nuts333.c:3942-4004, 4305-4459)."""
     accounts = [_acc(A), _acc(B, level=2), _acc(C, level=3), _acc(D, in_phrase="bounces in", out_phrase="rolls out")]
@@ -578,6 +627,7 @@ SCENARIOS = {
     "review": review,
     "prompts": prompts,
     "afk_bcast": afk_bcast,
+    "clones": clones,
     "rooms": rooms,
     "login_paths": login_paths,
     "capacity": capacity,
