@@ -9,11 +9,12 @@
  *
  * Scope: exactly the rows of SURVEY.md section 8(a) plus what a client needs to get
  * there -- accept, the 3-stage login, look, go, the speech commands (say shout tell
- * emote semote pemote echo), the toggles that change fan-out results (colour ignall
- * ignshout igntell vis invis prompt mode), review/revtell, version, and the NUTS netlink
- * verbs config #5 exercises.  Every other command name is recognised (so level gating
- * behaves) and answered with a notice.  Boards, mail, bans, clones, editor, pager state,
- * timers and admin commands are out of scope.
+ * emote semote pemote echo bcast wizshout), everything that changes fan-out results
+ * (colour ignall ignshout igntell vis invis prompt mode afk, clones and their commands),
+ * review/revtell, version, cls, and the NUTS netlink verbs config #5 exercises.  Every
+ * other command name is recognised (so level gating behaves) and answered with a notice.
+ * Boards, mail, ban administration, editor, pager state, timers and admin commands are out
+ * of scope.
  *
  * Same algorithmic shape as the reference where the path is concerned: one select() loop,
  * one read() per ready socket per wake-up, first-line-only framing, per-recipient
