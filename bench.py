@@ -172,12 +172,18 @@ def main() -> int:
     total = args.steps * args.lines_per_step
     warm = args.warmup * args.lines_per_step
 
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
     def barrier():
+        """Barrier + device sync on both sides of the timed region, as the contract asks.  No replica
+        queues GPU work, so the sync is a formality; each rank only ever touches ITS OWN device
+        (LOCAL_RANK), and none at all if there are fewer devices than ranks."""
         if dist is not None:
             dist.barrier()
         try:
             import torch
-            if torch.cuda.is_available():
+            if torch.cuda.device_count() > local_rank:     # device_count() does not initialise the GPU
+                torch.cuda.set_device(local_rank)
                 torch.cuda.synchronize()
         except Exception:
             pass

@@ -68,6 +68,7 @@ def plan(quick: bool) -> list[tuple[str, callable]]:
         ("config2_colour_on", lambda b: workloads.config2(lines=20_000 // q, warmup=1000, colour=1, binary=b)),
         ("config2_all_send", lambda b: workloads.config2(lines=20_000 // q, warmup=1000, all_send=True, binary=b)),
         ("config3", lambda b: workloads.config3(per_client=200 // q, binary=b)),
+        ("config3_six_rooms", lambda b: workloads.config3(per_client=200 // q, six_rooms=True, binary=b)),
         ("config4", lambda b: workloads.config4(lines=1000 // q, n=1000 // (4 if quick else 1), warmup=20, binary=b)),
         ("config4_colour_on", lambda b: workloads.config4(lines=1000 // q, n=1000 // (4 if quick else 1), warmup=20, colour=1, binary=b)),
         ("config5", lambda b: workloads.config5(lines=1000 // q, binary=b)),

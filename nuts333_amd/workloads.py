@@ -195,12 +195,12 @@ def _server_cpu(pin: bool, k: int = 0) -> int | None:
 
 
 def _run_single(build: Callable[[Spec, int], None], accounts, *, binary: Path, pin: bool, workdir: Path | None,
-                timeout_s: float, max_users: int = 1100, colour: int = 0) -> dict:
+                timeout_s: float, max_users: int = 1100, colour: int = 0, rooms=pv.DEFAULT_ROOMS) -> dict:
     tmp = Path(tempfile.mkdtemp(prefix="nuts333_", dir=workdir))
     talker = None
     try:
         ports = free_ports(3)
-        cfg = pv.TalkerConfig(mainport=ports[0], wizport=ports[1], linkport=ports[2], max_users=max_users)
+        cfg = pv.TalkerConfig(mainport=ports[0], wizport=ports[1], linkport=ports[2], max_users=max_users, rooms=rooms)
         talker = _boot(tmp, cfg, accounts, binary, _server_cpu(pin))
         spec = Spec()
         build(spec, ports[0])
@@ -247,10 +247,12 @@ def config2(lines: int = 20_000, n: int = 10, *, colour: int = 0, all_send: bool
     return res
 
 
-def config3(per_client: int = 200, n: int = 100, *, seed: int = 333, binary: Path, pin: bool = True, workdir=None,
-            timeout_s: float = 600.0) -> dict:
-    """n clients spread evenly over the 5 rooms; seeded 70/20/10 say/.shout/.tell mix from every client."""
-    rooms = [r.name for r in pv.DEFAULT_ROOMS]
+def config3(per_client: int = 200, n: int = 100, *, seed: int = 333, six_rooms: bool = False, binary: Path,
+            pin: bool = True, workdir=None, timeout_s: float = 600.0) -> dict:
+    """n clients spread evenly over the rooms (5 as shipped, or 6 with the ``shop``); seeded 70/20/10
+    say/.shout/.tell mix from every client."""
+    room_set = pv.SIX_ROOMS if six_rooms else pv.DEFAULT_ROOMS
+    rooms = [r.name for r in room_set]
     room_of = [rooms[i % len(rooms)] for i in range(n)]
     accounts = [pv.Account(pv.bot_name(i), level=2 if room_of[i] == "wizroom" else 1) for i in range(n)]
     rng = random.Random(seed)
@@ -274,8 +276,9 @@ def config3(per_client: int = 200, n: int = 100, *, seed: int = 333, binary: Pat
                     tgt = rng.choice([r for r in ids if r != s])
                     spec.add_line(s, f".tell {pv.bot_name(tgt)} {text}", [tgt])
 
-    res = _run_single(build, accounts, binary=binary, pin=pin, workdir=workdir, timeout_s=timeout_s, max_users=n + 10)
-    res["workload"] = f"config3: {n} clients over 5 rooms, {per_client} lines each, 70/20/10 say/shout/tell, seed {seed}"
+    res = _run_single(build, accounts, binary=binary, pin=pin, workdir=workdir, timeout_s=timeout_s, max_users=n + 10,
+                      rooms=room_set)
+    res["workload"] = f"config3: {n} clients over {len(rooms)} rooms, {per_client} lines each, 70/20/10 say/shout/tell, seed {seed}"
     return res
 
 

@@ -173,6 +173,12 @@ def test_config3_mixed_schedule_is_seeded_and_exact(port_binary):
     assert c["expected_deliveries"] != a["expected_deliveries"]
 
 
+def test_config3_six_room_variant(port_binary):
+    res = workloads.config3(per_client=5, n=24, six_rooms=True, binary=port_binary)
+    _check(res)
+    assert "6 rooms" in res["workload"]
+
+
 def test_config4_shout_fan_out(port_binary):
     res = workloads.config4(lines=20, n=120, warmup=2, binary=port_binary)
     _check(res)
