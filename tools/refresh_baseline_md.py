@@ -55,6 +55,11 @@ write cost by ≈45 % through cache-line migration, an artefact of loopback).
 
 {table('baseline_r01_mi355xhost_reference.md')}
 
+BASELINE.json words configuration #3 as "all 6 rooms"; the shipped config has five plus an orphan `shop.R`
+(SURVEY.md §4). Both variants, same host (the six-room one adds `shop` off the hallway):
+
+{table('baseline_r01_mi355xhost_config3_rooms.md')}
+
 Same host, reference compiled **without** optimisation (what the reference's own `build` script produces):
 
 {table('baseline_r01_mi355xhost_reference_O0.md')}
