@@ -69,6 +69,12 @@ class Client:
                 if not d:
                     raise ScriptError(f"client {self.key}: server closed; have {bytes(self.buf)!r}")
                 self.buf += d
+                # the talker never sets TCP_NODELAY: its second small write to us (the trailing colour
+                # reset) waits for our ACK, which the kernel would delay by 40 ms.  Ack at once.
+                try:
+                    self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_QUICKACK, 1)
+                except OSError:
+                    pass
         out = bytes(self.buf)
         self.buf.clear()
         return out
@@ -340,10 +346,21 @@ class Session:
             recv[key] = mine + recv.get(key, b"")
             self._record({"op": "line", "actor": key, "send": text, **({"note": note} if note else {})}, recv)
             return
-        # wait for the first byte of the actor's own output before syncing: the .version line
-        # must not share a read() with this one
-        first = c.read_until(lambda b: len(b) > 0)
-        recv = self._collect(c, first)
+        # The sync command must not share a read() with this line (the talker would drop it), so the
+        # talker has to consume the line first.  Not every line produces output for its sender (an
+        # emote by a user who ignores everyone, a clone told to hear nothing), so instead of waiting
+        # for output: wait until the line sits in the talker's receive queue (our send queue is
+        # acknowledged empty), then let ANOTHER client do two round trips -- the talker serves every
+        # ready socket per select() pass, so after the second reply the pass that held our line is over.
+        helper = next((h for h in self.clients.values() if h is not c and h.logged_in and h.can_sync), None)
+        if helper is None or not (c.logged_in and c.can_sync):
+            first = c.read_until(lambda b: len(b) > 0)
+            recv = self._collect(c, first)
+        else:
+            self._await_acked(c)
+            early = self._sync(helper) + self._sync(helper)
+            recv = self._collect(c)
+            recv[helper.key] = early + recv.get(helper.key, b"")
         what = {"op": "line", "actor": key, "send": text}
         if note:
             what["note"] = note
@@ -363,6 +380,17 @@ class Session:
             first = c.read_until(lambda b: len(b) > 0)
         recv = self._collect(c, first)
         self._record({"op": "raw", "actor": key, "send": [ch.decode("latin-1") for ch in chunks], "note": note}, recv)
+
+    @staticmethod
+    def _await_acked(c: Client, timeout: float = 5.0) -> None:
+        """Block until everything we sent has been acknowledged by the peer's TCP stack."""
+        import fcntl, struct, termios
+        deadline = time.monotonic() + timeout
+        while time.monotonic() < deadline:
+            if struct.unpack("i", fcntl.ioctl(c.sock.fileno(), termios.TIOCOUTQ, b"\0\0\0\0"))[0] == 0:
+                return
+            time.sleep(0.0002)
+        raise ScriptError(f"client {c.key}: data never acknowledged")
 
     def _settle(self, c: Client, quiet: float = 0.05) -> None:
         """Wait until the talker has read the bytes we just sent (its socket receive queue is
