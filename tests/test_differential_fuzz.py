@@ -37,6 +37,13 @@ def random_text(rng: random.Random) -> str:
             parts.append(rng.choice(["~", "~~", "~F", "/", "~zz"]))
         else:
             parts.append(rng.choice(WORDS))
+    x = rng.random()
+    if x < 0.04:
+        parts.insert(rng.randrange(len(parts) + 1), "w" * rng.choice([39, 40, 41, 85]))    # wordfind's 39-char slots
+    elif x < 0.08:
+        parts += [f"w{j}" for j in range(rng.choice([9, 10, 11, 14]))]                     # ... and its ten of them
+    elif x < 0.10:
+        parts.append("long" * rng.choice([50, 120, 230]))                                  # review ring cut, write chunking
     text = " ".join(parts)
     text += rng.choice(["", "", "", "?", "!"])
     return text
@@ -89,7 +96,7 @@ def make_script(seed: int):
             line = rng.choice([".", ".bogus", ".say", ".tell", ".shout", ".cls"])
             if line == ".":
                 continue        # the repeat buffer is overwritten by the sync command; covered in framing.json
-        steps.append((k, line[:200], flags))
+        steps.append((k, line[:950], flags))
 
     def script(s):
         for k, n, c in zip(KEYS, NAMES, colour0):
