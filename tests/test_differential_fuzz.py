@@ -122,3 +122,60 @@ def test_random_sessions_agree(seed, ref_binary, port_binary, monkeypatch):
     monkeypatch.setenv("NUTS_PORT_FAST", "1")
     fast = run_scenario(name, port_binary)["steps"]
     assert fast == ref, f"seed {seed}: fast mode diverges"
+
+
+# ---------------------------------------------------------------- two talkers, mixed implementations
+def make_netlink_script(seed: int):
+    """Alice (talker 0) travels to talker 1 and stays; everybody talks at random."""
+    rng = random.Random(seed)
+    base = scenarios.netlink()
+    colour = {"a": False, "b": False, "c": True, "d": False}
+    steps = []
+    for _ in range(45):
+        k = rng.choice("aaabbcd")
+        r = rng.random()
+        flags = {}
+        if r < 0.35:
+            text = random_text(rng)
+            line = text if text[0] not in ".;!<>-#" else "x" + text
+        elif r < 0.55:
+            line = ".shout " + random_text(rng)
+        elif r < 0.75:
+            line = ".tell " + rng.choice(["alice", "bobby", "carol", "dave", "nobody"]) + " " + random_text(rng)
+        elif r < 0.85:
+            line = rng.choice([";", "#"]) + random_text(rng)
+        elif r < 0.92:
+            line = rng.choice([".look", ".review", ".ignshout", ".igntell"])
+        else:
+            line = ".colour"
+            colour[k] = not colour[k]
+            flags = {"colour": colour[k]}
+        steps.append((k, line[:300], flags))
+
+    def script(s):
+        s.connect("a", talker=0); s.login("a", "Alice")
+        s.connect("d", talker=0); s.login("d", "Dave")
+        s.connect("b", talker=1); s.login("b", "Bobby")
+        s.connect("c", talker=1); s.login("c", "Carol", colour=True)
+        for hop in pv.WALKS["lounge"]:
+            s.line("b", f".go {hop}")
+            s.line("c", f".go {hop}")
+        s.line("a", ".go talker2", expect=b"has been set yet.\n\r")
+        for k, line, flags in steps:
+            s.line(k, line, **flags)
+
+    return {**base, "script": script}
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("seed", [333, 1996])
+def test_random_netlink_sessions_agree_across_implementations(seed, ref_binary, port_binary, monkeypatch):
+    name = f"__nlfuzz_{seed}"
+    monkeypatch.setitem(scenarios.SCENARIOS, name, lambda: make_netlink_script(seed))
+    ref = run_scenario(name, [ref_binary, ref_binary])["steps"]
+    for bins in ([port_binary, port_binary], [port_binary, ref_binary], [ref_binary, port_binary]):
+        got = run_scenario(name, bins)["steps"]
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert a == b, (f"seed {seed}, talkers {[x.name for x in bins]}, step {i}: {a.get('actor')} sent {a.get('send')!r}\n"
+                            f" reference: {a['recv']}\n got      : {b['recv']}")
+        assert len(got) == len(ref)
