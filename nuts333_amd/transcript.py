@@ -376,9 +376,18 @@ class Session:
             if i + 1 < len(chunks):
                 # let the talker consume this segment on its own before the next is sent
                 self._settle(c)
-        if expect_output:
-            first = c.read_until(lambda b: len(b) > 0)
-        recv = self._collect(c, first)
+        helper = next((h for h in self.clients.values() if h is not c and h.logged_in and h.can_sync), None)
+        if helper is not None and c.logged_in and c.can_sync:
+            # as in line(): make sure the talker has consumed the last segment before the sync command is sent
+            # (echoed characters of an earlier segment must not be mistaken for the reply to the last one)
+            self._await_acked(c)
+            early = self._sync(helper) + self._sync(helper)
+            recv = self._collect(c)
+            recv[helper.key] = early + recv.get(helper.key, b"")
+        else:
+            if expect_output:
+                first = c.read_until(lambda b: len(b) > 0)
+            recv = self._collect(c, first)
         self._record({"op": "raw", "actor": key, "send": [ch.decode("latin-1") for ch in chunks], "note": note}, recv)
 
     @staticmethod
@@ -391,6 +400,22 @@ class Session:
                 return
             time.sleep(0.0002)
         raise ScriptError(f"client {c.key}: data never acknowledged")
+
+    def raw_dialog(self, key: str, chunks: Iterable[bytes], expect: bytes, note: str = "", logged_in: bool | None = None) -> None:
+        """Pre-login conversation typed in pieces (a character-mode client): send the chunks one segment at
+        a time, then read up to ``expect``."""
+        c = self.clients[key]
+        chunks = list(chunks)
+        for i, ch in enumerate(chunks):
+            c.send_raw(ch)
+            if i + 1 < len(chunks):
+                self._settle(c)
+        mine = c.read_until(expect)
+        if logged_in is not None:
+            c.logged_in = logged_in
+        recv = self._collect(None)
+        recv[key] = mine + recv.get(key, b"")
+        self._record({"op": "raw", "actor": key, "send": [ch.decode("latin-1") for ch in chunks], "note": note}, recv)
 
     def _settle(self, c: Client, quiet: float = 0.05) -> None:
         """Wait until the talker has read the bytes we just sent (its socket receive queue is

@@ -1125,6 +1125,11 @@ static void exec_com(struct user *u, char *inpstr)
         else { u->colour = 1; write_user(u, "Colour ~FGON.\n"); }
         if (u->room < 0) prompt(u);
         break;
+    case NP_CHARECHO:                                                                                 /* c:6881-6893 */
+        write_user(u, u->charmode_echo ? "Echoing for character mode clients ~FROFF.\n" : "Echoing for character mode clients ~FGON.\n");
+        u->charmode_echo = !u->charmode_echo;
+        if (u->room < 0) prompt(u);
+        break;
     case NP_IGNSHOUT:                                                                                 /* c:7484-7494 */
         write_user(u, u->ignshout ? "You are no longer ignoring shouts and shout emotes.\n"
                                   : "You are now ignoring shouts and shout emotes.\n");

@@ -16,6 +16,7 @@ What they pin, by reference function:
   prompt        prompt() in speech and command mode                             c:2174-2197
   afk_bcast     the AFK branch of the main loop (incl. locked sessions), bcast (force_listen),  c:180-203, 4772-4788, 6527-6565,
                 wizshout (write_level), cls                                              7409-7454, 2636-2642
+  charecho      server-side echo for character-mode clients                                      c:369-399, 6881-6893
   clones        the clone branch of write_room_except: relay to the owner, hear all/swears/      c:1416-1426, 4085-4090, 7100-7357,
                 nothing, csay, switch, destroy, clean-up at logout                        2870-2882
   rooms         go / move_user / look: adjacency, prefix names, teleport, private     c:3942-4004, 4305-4459, 2412-2421
@@ -261,7 +262,7 @@ def review():
 
 
 def prompts():
-    accounts = [_acc(A, prompt=1), _acc(B, command_mode=1), _acc(C, prompt=1, colour=1)]
+    accounts = [_acc(A, prompt=1), _acc(B, command_mode=1, level=3), _acc(C, prompt=1, colour=1, level=3)]
     pa = rb"<\d\d:\d\d, \d\d:\d\d, Alice>\n\r"
     pc = rb"\x1b\[36m<\d\d:\d\d, \d\d:\d\d, Carol>\x1b\[0m\n\r\x1b\[0m"
     pc_invis = rb"\x1b\[36m<\d\d:\d\d, \d\d:\d\d, Carol\+>\x1b\[0m\n\r\x1b\[0m"
@@ -278,6 +279,12 @@ def prompts():
         s.line("b", "back in speech mode")
         s.line("a", ".prompt", prompt_re=b"")
         s.line("a", "no prompt now")
+        s.line("c", ".invis", prompt_re=pc_invis, note="an invisible user's prompt carries a plus sign")
+        s.line("c", "still prompted")
+        s.line("c", ".vis", prompt_re=pc)
+        s.line("b", ".mode", sync_suffix=b"COM> ")
+        s.line("b", "invis", sync_suffix=b"COM+> ")
+        s.line("b", "look")
 
     return {}, accounts, script
 
@@ -365,6 +372,29 @@ def clones():
         s.line("a", "the owner left, the clones went with him")
 
     return {"max_clones": 2}, accounts, script
+
+
+def charecho():
+    """Character-mode clients with server-side echo (nuts333.c:369-399, 6881-6893): typed bytes are echoed raw,
+    DEL/BS come back as "\\b \\b", the terminator as a newline; nothing is echoed while a password is typed."""
+    accounts = [_acc(A, charmode_echo=1), _acc(B)]
+    look_end = b"has been set yet.\n\r"
+    pw_prompt = b"Give me a password: \xff\xfb\x01"
+
+    def script(s):
+        s.connect("b"); s.login("b", B)
+        s.connect("a")
+        s.raw_dialog("a", [b"ali", b"ce\n"], pw_prompt, note="name typed in pieces: the account's echo flag is not loaded yet")
+        s.raw_dialog("a", [b"te", b"st\n"], look_end, logged_in=True, note="password typed in pieces: never echoed")
+        s.raw("a", [b"he", b"l\x7flo", b" wor\x08\x08\x08all\n"], note="echo, erase, echo, newline")
+        s.raw("a", [b"x", b"\x7f\x7f\x7fy\n"], note="erasing past the start echoes only what was erased")
+        s.raw("a", [b"whole line at once\n"], note="a complete line is not character mode: no echo")
+        s.line("a", ".charecho")
+        s.raw("a", [b"qu", b"iet\n"], note="echo off")
+        s.line("b", ".charecho")
+        s.raw("b", [b"lo", b"ud\n"], note="echo on for bobby")
+
+    return {}, accounts, script
 
 
 def rooms():
@@ -627,6 +657,7 @@ SCENARIOS = {
     "review": review,
     "prompts": prompts,
     "afk_bcast": afk_bcast,
+    "charecho": charecho,
     "clones": clones,
     "rooms": rooms,
     "login_paths": login_paths,

@@ -38,7 +38,7 @@ def abort_on_report(monkeypatch):
     monkeypatch.setenv("UBSAN_OPTIONS", "halt_on_error=1:print_stacktrace=1")
 
 
-@pytest.mark.parametrize("name", ["framing", "markup", "review", "login_paths", "clones", "afk_bcast", "rooms", "netlink",
+@pytest.mark.parametrize("name", ["framing", "charecho", "markup", "review", "login_paths", "clones", "afk_bcast", "rooms", "netlink",
                                   "netlink_wire_accept", "netlink_wire_dial"])
 def test_restatement_is_clean_under_asan_ubsan(name, asan_talker):
     gold = json.loads((REPO / "tests" / "golden" / f"{name}.json").read_text())["steps"]
@@ -55,7 +55,7 @@ def test_load_generator_is_clean_under_asan_ubsan(asan_talker, asan_loadgen, mon
 
 
 # ---------------------------------------------------------------- the reference itself, under ASan
-SINGLE_TALKER = ["afk_bcast", "speech_colour_off", "speech_colour_mixed", "markup", "filters", "errors", "swearing", "framing",
+SINGLE_TALKER = ["charecho", "afk_bcast", "speech_colour_off", "speech_colour_mixed", "markup", "filters", "errors", "swearing", "framing",
                  "review", "prompts", "rooms", "login_paths", "capacity", "netlink_wire_dial"]
 
 

@@ -93,7 +93,7 @@ Restatement:
 
 The three changes `INTEGRATION.md` §3 proposes — transduce once per colour variant instead of once per recipient,
 send the trailing colour reset in the same `write(2)`, `TCP_NODELAY` on netlink sockets — switched on in the
-restatement. The bytes on every socket are unchanged (all 17 recorded sessions replay byte-exact in this mode,
+restatement. The bytes on every socket are unchanged (all 18 recorded sessions replay byte-exact in this mode,
 `tests/test_parity_transcripts.py`); only the work differs.
 
 {fast_table}
