@@ -9,19 +9,28 @@ oracle/_ref/nuts333 is present, else our restatement oracle/_build/talker_port) 
 closed-loop load generator, and says so in every field.
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line.
-  * a "step" is one batch of ``--lines-per-step`` input lines pushed through the hot path
-    (read -> parse -> say -> per-recipient transduce + write(2)); the default K x L is exactly
-    BASELINE configs[1]: 10 clients in one room, client 0 says 20,000 lines, 9 recipients each;
+  * HEADLINE workload = BASELINE configs[3], the largest single-talker configuration: 1000 clients in one
+    room, client 0 ``.shout``s, 999 recipients per line (the metric is quoted "at N clients" without an N;
+    select(FD_SETSIZE), nuts333.c:94, caps N just above 1000).  A "step" is one batch of
+    ``--lines-per-step`` input lines pushed through the hot path (select -> read -> parse -> shout ->
+    per-recipient transduce + write(2)); the default K x L = 10 x 100 = the configuration's 1,000 lines.
   * W warm-up batches run untimed first, inside the same session;
   * the timed region is the load generator's own window (first send -> last expected
-    delivery), bracketed by a barrier on both sides when N > 1; MAX over ranks;
+    delivery), bracketed by a barrier on both sides when N > 1; MAX over ranks.  There is no
+    ``torch.cuda.synchronize()`` around it: no rank queues GPU work, and initialising N devices in a
+    process that is about to fork talkers buys nothing.
   * N > 1 = N independent talker replicas, one per rank ("replicas only"): the
     path does not shard and there is no collective on it.  ``--gpus`` only counts replicas;
     no GPU is used by any of them.
-  * ``roofline`` is the host system-call ceiling, not HBM/MFMA: achieved = write(2)-bearing
-    lines per second through the talker; peak = the same number of 67-byte writes issued
-    by a loop that does nothing else (loadgen --probe-fanout), priced by its CPU time per write.
-  * ``cpu_baseline`` is the same run by construction (the CPU path is the only path).
+  * ``configs`` = every BASELINE configuration (#1, #2, #3, #5 at their formal sizes, plus the headline #4),
+    each with delivered == expected per client (N = 1, rank 0 only; skipped by ``--no-extras``).
+  * ``roofline`` is the host system-call ceiling, not HBM/MFMA: achieved = lines written per second by
+    the talker; peak = what one core reaches when it does ONLY the system calls the algorithm needs per
+    input line -- 1 select(FD_SETSIZE) + 1 read + (recipients + 1) write(2) -- measured by
+    ``loadgen --probe-line`` in a closed loop (CPU time) and in an open loop (wall clock: a demonstrated
+    rate); the quoted peak is the lower of the two.  The write-only figure of round 1 stays beside it.
+  * ``cpu_baseline`` is the same run by construction (the CPU path is the only path);
+    ``cpu_baseline_port`` is the independent second number: our restatement on the same workload and size.
 """
 from __future__ import annotations
 
@@ -31,6 +40,7 @@ import os
 import subprocess
 import sys
 import time
+import traceback
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent
@@ -41,6 +51,10 @@ from nuts333_amd.talker import PORT_BINARY, REF_BINARY  # noqa: E402
 
 METRIC = "delivered_broadcast_lines_per_s"
 UNIT = "lines/s"
+
+#: workload -> (default lines per step, what one "line" is)
+DEFAULT_LINES_PER_STEP = {"config1": 1000, "config2": 2000, "config2_all": 2000, "config3": 2000, "config4": 100, "config5": 100}
+WORKLOADS = list(DEFAULT_LINES_PER_STEP)
 
 
 def ensure_built() -> None:
@@ -61,21 +75,98 @@ def partition_cpus(rank: int, world: int) -> list[int]:
 
 
 def run_workload(name: str, total_lines: int, warm_lines: int, binary: Path, pin: bool) -> dict:
+    if name == "config1":
+        return workloads.config1(lines=total_lines, warmup=warm_lines, binary=binary, pin=pin)
     if name == "config2":
         return workloads.config2(lines=total_lines, warmup=warm_lines, binary=binary, pin=pin)
     if name == "config2_all":
         return workloads.config2(lines=total_lines, warmup=warm_lines, all_send=True, binary=binary, pin=pin)
+    if name == "config3":           # 100 clients: a "line" is one input line of the mixed schedule, 100 per round
+        return workloads.config3(per_client=max(1, total_lines // 100), warmup=warm_lines // 100, binary=binary, pin=pin)
     if name == "config4":
         return workloads.config4(lines=total_lines, warmup=warm_lines, binary=binary, pin=pin)
-    if name == "config1":
-        return workloads.config1(lines=total_lines, warmup=warm_lines, binary=binary, pin=pin)
+    if name == "config5":           # a "line" is one shout by each of the two senders
+        return workloads.config5(lines=total_lines, warmup=warm_lines, binary=binary, pin=pin)
     raise SystemExit(f"unknown workload {name}")
+
+
+def config_entry(name: str, res: dict) -> dict:
+    srv = res["servers"][0]
+    out = {"name": name, "n": res["clients"], "workload": res["workload"],
+           "delivered_lines_per_s": round(res["delivered_lines_per_s"], 1),
+           "input_lines_per_s": round(res["input_lines_per_s"], 1),
+           "input_lines": res["input_lines"], "delivered": res["deliveries"], "expected_delivered": res["expected_deliveries"],
+           "server_cpu_us_per_line": round(srv["cpu_us_per_written_line"], 3),
+           "server_busy_frac": round(srv["busy_frac"], 3),
+           "ack_latency_us_p50": res["ack_latency_us"]["p50"], "wall_s": round(res["wall_s"], 4),
+           "exact": bool(res["exact"])}
+    if "netlink" in res:
+        out["netlink"] = res["netlink"]
+        out["exact"] = bool(res["exact"] and res["netlink"]["exact"])
+    return out
+
+
+def all_configs(binary: Path, pin: bool, headline_name: str, headline: dict) -> list[dict]:
+    """BASELINE.json's five configurations at their formal sizes (nuts333_amd/baseline.py).  The headline run is
+    reused for its own slot; #5 takes ~15-30 s because neither talker sets TCP_NODELAY on the link (nuts333.c:1266)."""
+    plan = [("config1", lambda: workloads.config1(lines=10_000, warmup=500, binary=binary, pin=pin)),
+            ("config2", lambda: workloads.config2(lines=20_000, warmup=1000, binary=binary, pin=pin)),
+            ("config3", lambda: workloads.config3(per_client=200, warmup=2, binary=binary, pin=pin)),
+            ("config4", lambda: workloads.config4(lines=1000, warmup=20, binary=binary, pin=pin)),
+            ("config5", lambda: workloads.config5(lines=1000, binary=binary, pin=pin))]
+    out = []
+    for name, fn in plan:
+        t = time.time()
+        res = headline if name == headline_name else fn()
+        e = config_entry(name, res)
+        e["is_headline_run"] = name == headline_name
+        out.append(e)
+        print(f"[bench] {name}: {e['delivered_lines_per_s']:,.0f} delivered/s, {e['input_lines_per_s']:,.0f} input/s, "
+              f"exact={e['exact']} ({time.time() - t:.1f}s)", file=sys.stderr, flush=True)
+    return out
+
+
+def syscall_roofline(res: dict, achieved: float) -> dict:
+    """Host system-call roofline for the headline run (see module docstring).  Three probe legs, same message size,
+    same number of sockets as the talker wrote to per input line, talker core / receiver cores placed as in the run."""
+    cpus = sorted(os.sched_getaffinity(0))
+    recipients = max(0, round(res["expected_deliveries"] / max(1, res["input_lines"])))
+    size = max(2, round(res["bytes_per_line"]))
+    rounds = max(100, 300_000 // (recipients + 1))
+    readers = max(1, min(4, len(cpus) - 1))
+    place = [str(cpus[0]), ",".join(str(c) for c in cpus[1:1 + readers])] if len(cpus) >= 2 else []
+
+    def leg(selread: int, open_loop: int) -> dict:
+        cmd = [str(workloads.LOADGEN_BIN), "--probe-line", str(size), str(recipients), str(rounds), str(selread),
+               str(open_loop), str(readers)] + place
+        return json.loads(subprocess.run(cmd, check=True, stdout=subprocess.PIPE).stdout)
+
+    write_only = leg(0, 0)
+    closed = leg(1, 0)
+    opened = leg(1, 1)
+    peak_cpu = closed["written_lines_per_s_cpu"]
+    peak_demo = opened["written_lines_per_s_wall"]
+    peak = min(peak_cpu, peak_demo)
+    peak_wo = write_only["written_lines_per_s_cpu"]
+    return {"bound": "host-syscall", "achieved": round(achieved, 1), "peak": round(peak, 1),
+            "unit": "lines written/s on one core (1 write(2) each; + 1 select + 1 read per input line)",
+            "frac": round(achieved / peak, 3), "traffic": None,
+            "peak_source": "closed-loop CPU time" if peak_cpu <= peak_demo else "open-loop wall clock (demonstrated)",
+            "peak_closed_loop_cpu_time": round(peak_cpu, 1), "peak_open_loop_wall_demonstrated": round(peak_demo, 1),
+            "peak_write_only": round(peak_wo, 1), "frac_write_only": round(achieved / peak_wo, 3),
+            "per_input_line": {"select": 1, "read": 1, "write": recipients + 1, "select_nfds": closed["select_nfds"],
+                               "probe_cpu_us_select_plus_read": round(closed["cpu_ns_select_read_per_line"] / 1e3, 3),
+                               "probe_cpu_us_per_write": round(closed["cpu_ns_per_write"] / 1e3, 4)},
+            "probe": {"write_only_closed": write_only, "full_closed": closed, "full_open": opened},
+            "note": "no HBM/MFMA roofline applies: no device kernel exists. peak = the lower of (a) 1e9 x writes / CPU ns "
+                    "of a loop doing only select(FD_SETSIZE)+read+writes per input line, closed loop like the run, and "
+                    "(b) the wall-clock rate the same loop reaches open-loop (a demonstrated rate, no extrapolation)"}
 
 
 def device_floor() -> dict | None:
     """What merely *touching* an MI355X costs, for the record: one tiny kernel + sync, and a
     host->device->host round trip the size of the largest broadcast (1000 x 69 B).  Torch only;
-    there is no custom kernel to time.  None when no GPU is visible."""
+    there is no custom kernel to time.  None when no GPU is visible.  Called LAST: it initialises HIP."""
     try:
         import torch
     except Exception:
@@ -127,11 +218,13 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1, help="number of independent talker replicas (no GPU is used)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--lines-per-step", type=int, default=2000)
-    ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config2_all", "config4"])
+    ap.add_argument("--lines-per-step", type=int, default=0, help="0 = the workload's default " + str(DEFAULT_LINES_PER_STEP))
+    ap.add_argument("--workload", default="config4", choices=WORKLOADS)
     ap.add_argument("--binary", default="auto", choices=["auto", "reference", "port"])
-    ap.add_argument("--no-extras", action="store_true", help="skip the syscall probe / port comparison / device floor")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="headline run only: skip the other four configurations, the syscall probe, the port comparison and the device floor")
     args = ap.parse_args()
+    lines_per_step = args.lines_per_step or DEFAULT_LINES_PER_STEP[args.workload]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,7 +241,8 @@ def main() -> int:
 
     dist = None
     if world > 1:
-        import torch.distributed as dist  # gloo: the replicas exchange two scalars, nothing on the data path
+        import torch
+        import torch.distributed as dist  # gloo: the replicas exchange a few scalars, nothing on the data path
         # gloo announces its mesh on stdout; the contract is ONE JSON line there, so lend it stderr
         sys.stdout.flush()
         saved = os.dup(1)
@@ -169,39 +263,44 @@ def main() -> int:
     pin = len(os.sched_getaffinity(0)) >= 2
     binary, kind = workloads.pick_binary(args.binary)
 
-    total = args.steps * args.lines_per_step
-    warm = args.warmup * args.lines_per_step
-
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    total = args.steps * lines_per_step
+    warm = args.warmup * lines_per_step
 
     def barrier():
-        """Barrier + device sync on both sides of the timed region, as the contract asks.  No replica
-        queues GPU work, so the sync is a formality; each rank only ever touches ITS OWN device
-        (LOCAL_RANK), and none at all if there are fewer devices than ranks."""
         if dist is not None:
             dist.barrier()
-        try:
-            import torch
-            if torch.cuda.device_count() > local_rank:     # device_count() does not initialise the GPU
-                torch.cuda.set_device(local_rank)
-                torch.cuda.synchronize()
-        except Exception:
-            pass
 
     barrier()
     t_outer0 = time.perf_counter()
-    res = run_workload(args.workload, total, warm, binary, pin)
+    res, failure = None, ""
+    try:
+        if os.environ.get("NUTS_BENCH_INJECT_FAILURE"):          # tests only: see test_bench_failed_replica_...
+            raise RuntimeError("injected failure")
+        res = run_workload(args.workload, total, warm, binary, pin)
+        if not res["exact"]:
+            failure = "delivered != expected: " + json.dumps({k: res[k] for k in ("deliveries", "expected_deliveries", "lines_total")})
+    except Exception:                           # a dead replica must not leave the others waiting in a collective
+        failure = traceback.format_exc()
     t_outer1 = time.perf_counter()
-    barrier()
-    if not res["exact"]:
-        print(json.dumps({"error": "delivered != expected", "result": res}), file=sys.stderr)
+    ok = 0.0 if failure else 1.0
+    if dist is not None:
+        flag = torch.tensor([ok], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # first collective after the run: everyone reaches it
+        ok = float(flag[0])
+    if failure:
+        print(f"[bench] rank {rank} failed: {failure}", file=sys.stderr, flush=True)
+    if ok < 1.0:
+        if dist is not None:
+            dist.destroy_process_group()
+        if rank == 0 and not failure:
+            print("[bench] another replica failed (see its stderr); no result line", file=sys.stderr, flush=True)
         return 1
+    barrier()
 
     wall = res["wall_s"]
     deliveries = res["deliveries"]
     written = res["lines_total"]
     if dist is not None:
-        import torch
         t = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall_max = float(t[0])
@@ -224,49 +323,43 @@ def main() -> int:
         "ms_per_step": round(wall_max / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": res["workload"], "lines_per_step": args.lines_per_step,
+        "config": {"workload": res["workload"], "baseline_config": args.workload, "clients": res["clients"],
+                   "lines_per_step": lines_per_step,
                    "implementation": kind, "binary": str(binary.relative_to(REPO)),
                    "parallelism": f"{world} independent talker replica(s); no GPU on the path",
                    "payload_bytes": workloads.PAYLOAD_LEN, "bytes_per_delivered_line": round(res["bytes_per_line"], 2)},
         "gpu_used": False,
         "classification": "misclassified / not graft-eligible (BASELINE.json north_star); CPU baseline only",
-        "delivered": int(deliveries_all), "expected_delivered": res["expected_deliveries"] * world if world > 1 else res["expected_deliveries"],
+        "delivered": int(deliveries_all), "expected_delivered": res["expected_deliveries"] * world,
         "input_lines_per_s": round(res["input_lines_per_s"], 1),
         "ack_latency_us": res["ack_latency_us"],
         "server_cpu_us_per_written_line": round(srv["cpu_us_per_written_line"], 3),
         "server_user_frac": srv["user_frac"], "server_busy_frac": round(srv["busy_frac"], 3),
+        "server_syscalls": {"read": srv.get("read_syscalls"), "write": srv.get("write_syscalls"),
+                            "per_input_line": {"read": round(srv["read_syscalls_per_input_line"], 3),
+                                               "write": round(srv["write_syscalls"] / max(1, res["input_lines"]), 3)}},
         "outer_wall_s": round(t_outer1 - t_outer0, 3), "login_s": res["login_s"],
     }
     baseline = {"value": round(res["delivered_lines_per_s"], 1), "unit": UNIT, "cores": 1, "kind": kind,
                 "sample": f"the timed run itself: {res['input_lines']} input lines, {res['deliveries']} deliveries, one replica"}
     roofline = None
     if not args.no_extras and world == 1:
-        cpus = sorted(os.sched_getaffinity(0))
-        recipients = max(1, res["expected_deliveries"] // max(1, res["input_lines"]))
-        rounds = max(200, 200_000 // recipients)
-        cmd = [str(workloads.LOADGEN_BIN), "--probe-fanout", str(round(res["bytes_per_line"])), str(recipients), str(rounds)]
-        if len(cpus) >= 2:
-            cmd += [str(cpus[0]), str(cpus[1])]
-        probe = json.loads(subprocess.run(cmd, check=True, stdout=subprocess.PIPE).stdout)
-        achieved = written_all / wall_max
-        # the talker is one thread on one core: its ceiling is what that core can issue when it does
-        # nothing but write(2) -- CPU time per write, not the probe's wall time (which includes its reader)
-        peak = 1e9 / probe["cpu_ns_per_write"]
-        roofline = {"bound": "host-syscall", "achieved": round(achieved, 1), "peak": round(peak, 1),
-                    "unit": "write(2)/s on one core", "frac": round(achieved / peak, 3), "traffic": None, "probe": probe,
-                    "note": "no HBM/MFMA roofline applies: no device kernel exists. peak = 1e9 / (CPU ns per closed-loop "
-                            "write(2) of the same size to the same number of loopback sockets, zero user-space work)"}
+        roofline = syscall_roofline(res, written_all / wall_max)
         if kind == "reference" and PORT_BINARY.exists():
-            p = workloads.config2(lines=5000, warmup=1000, binary=PORT_BINARY, pin=pin)
+            p = run_workload(args.workload, total, warm, PORT_BINARY, pin)
             out["cpu_baseline_port"] = {"value": round(p["delivered_lines_per_s"], 1), "unit": UNIT, "cores": 1, "kind": "port",
-                                        "sample": "config2, 5000 input lines", "exact": p["exact"]}
+                                        "sample": f"same workload and size as the timed run: {p['input_lines']} input lines, "
+                                                  f"{p['deliveries']} deliveries", "exact": p["exact"],
+                                        "server_cpu_us_per_written_line": round(p["servers"][0]["cpu_us_per_written_line"], 3)}
+        out["configs"] = all_configs(binary, pin, args.workload, res)
+        out["configs_all_exact"] = all(e["exact"] for e in out["configs"])
         out["device_floor"] = device_floor()
     out["roofline"] = roofline
     out["cpu_baseline"] = baseline
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
-    return 0
+    return 0 if out.get("configs_all_exact", True) else 1
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 """Formal CPU baseline: the five BASELINE.json configurations, three repetitions each, median.
 
     python -m nuts333_amd.baseline [--binary auto|reference|reference_O0|port] [--reps 3]
-                                   [--out profiles/baseline_r01_<host>.json] [--quick]
+                                   [--out profiles/baseline_rNN_<host>.json] [--quick]
 
 Reported per configuration: N; input lines/s; delivered lines/s;
 delivered == expected (per client); server user/sys CPU per written line; bytes per line; for
@@ -55,8 +55,13 @@ def median_of(runs: list[dict]) -> dict:
         "ack_latency_us_p99": round(med(lambda r: r["ack_latency_us"]["p99"]), 1),
         "login_s": round(med(lambda r: r["login_s"]), 3),
         "server_rss_peak_kb": max(r.get("server_rss_peak_kb", 0) for r in runs),
-        **({"netlink_frames_t2_to_t1": runs[0]["netlink_frames_t2_to_t1"],
-            "netlink_frames_t1_to_t2": runs[0]["netlink_frames_t1_to_t2"]} if "netlink_frames_t2_to_t1" in runs[0] else {}),
+        "read_syscalls_per_input_line": round(med(lambda r: srv(r)["read_syscalls_per_input_line"]), 4),
+        "write_syscalls_per_written_line": round(med(lambda r: srv(r)["write_syscalls_per_line"]), 4),
+        # configuration #5: link frames MEASURED in every repetition (workloads.config5), not modelled
+        **({"netlink_writes_t1_to_t2": [r["netlink"]["writes_t1_to_t2"] for r in runs],
+            "netlink_writes_t2_to_t1": [r["netlink"]["writes_t2_to_t1"] for r in runs],
+            "netlink_expected": {k: runs[0]["netlink"][k] for k in ("expected_act_frames", "expected_msg_frames", "expected_prm_frames")},
+            "netlink_exact": all(r["netlink"]["exact"] for r in runs)} if "netlink" in runs[0] else {}),
     }
 
 
@@ -67,8 +72,8 @@ def plan(quick: bool) -> list[tuple[str, callable]]:
         ("config2", lambda b: workloads.config2(lines=20_000 // q, warmup=1000, binary=b)),
         ("config2_colour_on", lambda b: workloads.config2(lines=20_000 // q, warmup=1000, colour=1, binary=b)),
         ("config2_all_send", lambda b: workloads.config2(lines=20_000 // q, warmup=1000, all_send=True, binary=b)),
-        ("config3", lambda b: workloads.config3(per_client=200 // q, binary=b)),
-        ("config3_six_rooms", lambda b: workloads.config3(per_client=200 // q, six_rooms=True, binary=b)),
+        ("config3", lambda b: workloads.config3(per_client=200 // q, warmup=2, binary=b)),
+        ("config3_six_rooms", lambda b: workloads.config3(per_client=200 // q, warmup=2, six_rooms=True, binary=b)),
         ("config4", lambda b: workloads.config4(lines=1000 // q, n=1000 // (4 if quick else 1), warmup=20, binary=b)),
         ("config4_colour_on", lambda b: workloads.config4(lines=1000 // q, n=1000 // (4 if quick else 1), warmup=20, colour=1, binary=b)),
         ("config5", lambda b: workloads.config5(lines=1000 // q, binary=b)),
@@ -124,7 +129,7 @@ def main(argv: list[str] | None = None) -> int:
         Path(args.out).write_text(text + "\n")
         Path(args.out).with_suffix(".md").write_text(to_markdown(doc))
     print(to_markdown(doc))
-    return 0 if all(m["all_exact"] for m in doc["results"].values()) else 1
+    return 0 if all(m["all_exact"] and m.get("netlink_exact", True) for m in doc["results"].values()) else 1
 
 
 if __name__ == "__main__":

@@ -552,71 +552,169 @@ static int probe_write(int bytes, long count) {
 }
 
 
-/* K connected loopback pairs, one spinning reader draining all of them, one writer doing
-   nothing but write(2) of BYTES to each socket in turn: the floor of the reference's
-   fan-out loop (nuts333.c:1409-1428 -> 1363) with zero user-space work. */
-struct fan_arg { int epfd; atomic_int stop; atomic_ullong rx; };
-static void *fan_reader(void *arg) {
-    struct fan_arg *fa = arg; char *buf = malloc(RBUF); struct epoll_event evs[256];
-    while (!atomic_load(&fa->stop)) {
-        int n = epoll_wait(fa->epfd, evs, 256, 0);
+/* ------------------------------------------------------------------ per-input-line syscall probe
+ *
+ * The floor of the reference's per-input-line work with ZERO user-space work:
+ *
+ *     select(FD_SETSIZE, &readmask, ...)        nuts333.c:94     one per input line, O(nfds) scan
+ *     read(sender, buf, ...)                    nuts333.c:136    one per input line
+ *     write(sender, ack) ; write(recipient_i)   nuts333.c:1363   1 + K per input line (say/shout: the
+ *                                                                sender's "You ...:" line goes first)
+ *
+ * One "talker" thread does exactly that and nothing else over K+1 connected loopback pairs; R reader
+ * threads play the synthetic clients the way the load generator's workers do (own epoll, busy-poll,
+ * TCP_QUICKACK re-armed).  Client 0 is the sender: it sends the next LINE-byte input line when its ack
+ * arrives -- the load generator's closed loop.
+ *
+ *   selread=0   write-only leg: the K+1 writes alone (round 1's figure, kept for comparison)
+ *   selread=1   full leg: select + read + K+1 writes
+ *   open=1      open loop: the sender keeps DEPTH lines in flight so select() never sleeps and the
+ *               talker thread never waits for a receiver: its WALL-clock rate is a demonstrated rate,
+ *               not a CPU-time extrapolation.
+ */
+#include <sys/resource.h>
+#include <sys/select.h>
+
+#define PROBE_MAX_READERS 16
+struct lp_reader { int epfd, cpu, sender_cfd, line, open_loop; atomic_int *stop; atomic_ullong rx; pthread_t tid; };
+
+static void *lp_reader_main(void *arg) {
+    struct lp_reader *rd = arg; char *buf = malloc(RBUF); struct epoll_event evs[256];
+    char line[1024]; memset(line, 'i', sizeof(line));
+    if (rd->cpu >= 0) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(rd->cpu, &set); pthread_setaffinity_np(pthread_self(), sizeof(set), &set); }
+    line[rd->line - 1] = '\n';
+    unsigned long long sender_rx = 0, sender_lines = 0; int ackbytes = rd->open_loop; /* reused: bytes per ack */
+    while (!atomic_load(rd->stop)) {
+        int n = epoll_wait(rd->epfd, evs, 256, 0);
         for (int i = 0; i < n; i++) {
-            int fd = evs[i].data.fd;
-            ssize_t r; unsigned long long got = 0;
+            int fd = evs[i].data.fd; ssize_t r; unsigned long long got = 0;
             while ((r = recv(fd, buf, RBUF, MSG_DONTWAIT)) > 0) got += (unsigned long long)r;
-            atomic_fetch_add(&fa->rx, got);
             int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_QUICKACK, &one, sizeof(one));
+            atomic_fetch_add(&rd->rx, got);
+            if (fd == rd->sender_cfd) {
+                /* one new input line per ack received, each its own segment (TCP_NODELAY on the client side) */
+                sender_rx += got;
+                while (sender_lines < sender_rx / (unsigned long long)ackbytes) {
+                    if (send(fd, line, (size_t)rd->line, MSG_NOSIGNAL) < 0 && errno != EAGAIN) break;
+                    sender_lines++;
+                }
+            }
         }
     }
     free(buf); return NULL;
 }
 
-static int probe_fanout(int bytes, int k, long rounds, int wcpu, int rcpu) {
+static int probe_line(int bytes, int k, long rounds, int selread, int open_loop, int nreaders, int wcpu, const int *rcpus, int nrcpus) {
+    const int LINE = 60, DEPTH = 32;        /* input line: 54-byte payload + ".shout" / newline, about 60 bytes */
+    if (nreaders < 1) nreaders = 1;
+    if (nreaders > PROBE_MAX_READERS) nreaders = PROBE_MAX_READERS;
+    if (bytes < 2 || bytes > 1000 || k < 0 || k + 8 >= FD_SETSIZE) { fprintf(stderr, "probe-line: bad sizes\n"); return 2; }
+    struct rlimit rl; if (!getrlimit(RLIMIT_NOFILE, &rl)) { rl.rlim_cur = rl.rlim_max; setrlimit(RLIMIT_NOFILE, &rl); }
     int ls = socket(AF_INET, SOCK_STREAM, 0); if (ls < 0) die("socket");
     struct sockaddr_in sa; memset(&sa, 0, sizeof(sa));
     sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
     if (bind(ls, (struct sockaddr *)&sa, sizeof(sa)) < 0) die("bind");
     socklen_t sl = sizeof(sa); getsockname(ls, (struct sockaddr *)&sa, &sl);
     listen(ls, 16);
-    int *wfd = calloc((size_t)k, sizeof(int));
-    struct fan_arg fa; fa.epfd = epoll_create1(0); atomic_init(&fa.stop, 0); atomic_init(&fa.rx, 0);
-    for (int i = 0; i < k; i++) {
-        int cfd = socket(AF_INET, SOCK_STREAM, 0);
-        if (connect(cfd, (struct sockaddr *)&sa, sizeof(sa)) < 0) die("connect");
-        wfd[i] = accept(ls, NULL, NULL); if (wfd[i] < 0) die("accept");
-        struct epoll_event ev; ev.events = EPOLLIN; ev.data.fd = cfd;
-        epoll_ctl(fa.epfd, EPOLL_CTL_ADD, cfd, &ev);
+    int nsock = k + 1;                       /* [0] = the sender, [1..k] = recipients */
+    int *wfd = calloc((size_t)nsock, sizeof(int));
+    atomic_int stop; atomic_init(&stop, 0);
+    struct lp_reader rd[PROBE_MAX_READERS];
+    for (int r = 0; r < nreaders; r++) {
+        rd[r].epfd = epoll_create1(0); rd[r].cpu = nrcpus ? rcpus[r % nrcpus] : -1; rd[r].sender_cfd = -1;
+        rd[r].line = LINE; rd[r].open_loop = bytes; rd[r].stop = &stop; atomic_init(&rd[r].rx, 0);
     }
-    pthread_t rt; pthread_create(&rt, NULL, fan_reader, &fa);
-    cpu_set_t set;
-    if (rcpu >= 0) { CPU_ZERO(&set); CPU_SET(rcpu, &set); pthread_setaffinity_np(rt, sizeof(set), &set); }
-    if (wcpu >= 0) { CPU_ZERO(&set); CPU_SET(wcpu, &set); pthread_setaffinity_np(pthread_self(), sizeof(set), &set); }
-    char *buf = malloc((size_t)bytes); memset(buf, 'x', (size_t)bytes); buf[bytes - 1] = '\n';
-    /* closed loop like the talker's single sender: a round of K writes, then wait until the
-       readers hold every byte, so each write is a full transmit + loopback receive + ACK */
-    unsigned long long want = 0; double cpu_ns = 0;
-    struct timespec c0, c1; uint64_t t0 = 0;
-    for (long r = -20; r < rounds; r++) {
-        if (r == 0) { t0 = now_ns(); cpu_ns = 0; }
-        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
-        for (int i = 0; i < k; i++) if (write(wfd[i], buf, (size_t)bytes) < 0) die("write");
-        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c1);
-        cpu_ns += (double)(c1.tv_sec - c0.tv_sec) * 1e9 + (double)(c1.tv_nsec - c0.tv_nsec);
-        want += (unsigned long long)bytes * (unsigned long long)k;
-        while (atomic_load(&fa.rx) < want) {}
+    int sender_cfd = -1;
+    for (int i = 0; i < nsock; i++) {
+        int cfd = socket(AF_INET, SOCK_STREAM, 0); if (cfd < 0) die("socket");
+        int one = 1; setsockopt(cfd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+        int rcv = 1 << 20; setsockopt(cfd, SOL_SOCKET, SO_RCVBUF, &rcv, sizeof(rcv));
+        if (connect(cfd, (struct sockaddr *)&sa, sizeof(sa)) < 0) die("connect");
+        int a = accept(ls, NULL, NULL); if (a < 0) die("accept");
+        /* the talker side must stay below FD_SETSIZE for select(); park the client side high */
+        int hi = fcntl(cfd, F_DUPFD, 2048); if (hi < 0) die("F_DUPFD (RLIMIT_NOFILE too low)");
+        close(cfd); cfd = hi;
+        if (a >= FD_SETSIZE) { fprintf(stderr, "probe-line: talker-side fd %d >= FD_SETSIZE\n", a); return 2; }
+        wfd[i] = a;                          /* blocking, no TCP_NODELAY: as the talker leaves its sockets */
+        setsockopt(cfd, IPPROTO_TCP, TCP_QUICKACK, &one, sizeof(one));
+        struct epoll_event ev; ev.events = EPOLLIN; ev.data.fd = cfd;
+        struct lp_reader *r = &rd[i % nreaders];
+        epoll_ctl(r->epfd, EPOLL_CTL_ADD, cfd, &ev);
+        if (i == 0) { sender_cfd = cfd; r->sender_cfd = cfd; }
+    }
+    for (int r = 0; r < nreaders; r++) pthread_create(&rd[r].tid, NULL, lp_reader_main, &rd[r]);
+    if (wcpu >= 0) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(wcpu, &set); pthread_setaffinity_np(pthread_self(), sizeof(set), &set); }
+    char *buf = malloc((size_t)bytes); memset(buf, 'x', (size_t)bytes); buf[bytes - 2] = '\n'; buf[bytes - 1] = '\r';
+    char in[1024], first[1024]; memset(first, 'i', sizeof(first)); first[LINE - 1] = '\n';
+    fd_set proto, mask; FD_ZERO(&proto); FD_SET(ls, &proto);
+    for (int i = 0; i < nsock; i++) FD_SET(wfd[i], &proto);
+    /* prime: in the closed loop one line in flight, in the open loop DEPTH of them; every ack then triggers one more */
+    int prime = selread ? (open_loop ? DEPTH : 1) : 0;
+    for (int i = 0; i < prime; i++) if (send(sender_cfd, first, (size_t)LINE, MSG_NOSIGNAL) < 0) die("prime send");
+    const long WARM = 20;
+    unsigned long long want = 0; struct timespec s0, s1, w1; uint64_t t0 = 0; double sel_ns = 0, wr_ns = 0;
+#define TS_NS(a, b) ((double)((b).tv_sec - (a).tv_sec) * 1e9 + (double)((b).tv_nsec - (a).tv_nsec))
+    for (long r = -WARM; r < rounds; r++) {
+        if (r == 0) { t0 = now_ns(); sel_ns = wr_ns = 0; }
+        /* CPU time is taken per section so that neither the write-only leg's wait below nor a sleep in select()
+           is charged; the three clock calls per round (~0.1 us each, a real system call for this clock) are
+           ours, not the talker's, and about one of them lands inside each section: the peak is understated by
+           that much, which matters only for small K */
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &s0);
+        if (selread) {
+            mask = proto;
+            if (select(FD_SETSIZE, &mask, NULL, NULL, NULL) < 0) die("select");
+            ssize_t got = read(wfd[0], in, (size_t)LINE);     /* lines are LINE bytes each: exactly one */
+            if (got <= 0) die("read");
+        }
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &s1);
+        for (int i = 0; i < nsock; i++) if (write(wfd[i], buf, (size_t)bytes) < 0) die("write");
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &w1);
+        if (selread) sel_ns += TS_NS(s0, s1);
+        wr_ns += TS_NS(s1, w1);
+        want += (unsigned long long)bytes * (unsigned long long)nsock;
+        if (!selread) {
+            /* write-only leg keeps round 1's closed loop: wait until the readers hold every byte */
+            unsigned long long have;
+            do { have = 0; for (int q = 0; q < nreaders; q++) have += atomic_load(&rd[q].rx); } while (have < want);
+        }
     }
     uint64_t t1 = now_ns();
-    double n = (double)rounds * (double)k;
-    printf("{\"probe\":\"fanout\",\"bytes\":%d,\"sockets\":%d,\"rounds\":%ld,\"wall_ns_per_write\":%.1f,\"cpu_ns_per_write\":%.1f,\"writes_per_s\":%.0f}\n",
-           bytes, k, rounds, (double)(t1 - t0) / n, cpu_ns / n, n / ((double)(t1 - t0) / 1e9));
-    atomic_store(&fa.stop, 1); pthread_join(rt, NULL);
-    return 0;
+    /* let the readers finish so the byte count can be checked */
+    unsigned long long total = (unsigned long long)(rounds + WARM) * (unsigned long long)bytes * (unsigned long long)nsock, have = 0;
+    uint64_t dl = now_ns() + 5000000000ull;
+    do { have = 0; for (int q = 0; q < nreaders; q++) have += atomic_load(&rd[q].rx); } while (have < total && now_ns() < dl);
+    atomic_store(&stop, 1);
+    for (int r = 0; r < nreaders; r++) pthread_join(rd[r].tid, NULL);
+    double cpu_ns = sel_ns + wr_ns;
+    double wall_ns = (double)(t1 - t0), nw = (double)rounds * (double)nsock;
+    printf("{\"probe\":\"line\",\"mode\":\"%s\",\"select_read\":%d,\"bytes\":%d,\"recipients\":%d,\"writes_per_line\":%d,"
+           "\"input_line_bytes\":%d,\"select_nfds\":%d,\"rounds\":%ld,\"readers\":%d,"
+           "\"cpu_ns_per_line\":%.1f,\"wall_ns_per_line\":%.1f,\"cpu_ns_select_read_per_line\":%.1f,"
+           "\"cpu_ns_per_write\":%.1f,\"cpu_ns_per_written_line\":%.1f,\"wall_ns_per_written_line\":%.1f,"
+           "\"written_lines_per_s_cpu\":%.0f,\"written_lines_per_s_wall\":%.0f,\"bytes_ok\":%s}\n",
+           open_loop ? "open" : "closed", selread, bytes, k, nsock, selread ? LINE : 0, selread ? FD_SETSIZE : 0, rounds, nreaders,
+           cpu_ns / (double)rounds, wall_ns / (double)rounds, sel_ns / (double)rounds,
+           wr_ns / nw, cpu_ns / nw, wall_ns / nw, nw / (cpu_ns / 1e9), nw / (wall_ns / 1e9), have >= total ? "true" : "false");
+    return have >= total ? 0 : 1;
+}
+
+/* round 1's CLI: `--probe-fanout BYTES K ROUNDS [WCPU [RCPU]]` = the closed-loop write-only leg over K sockets */
+static int probe_fanout(int bytes, int k, long rounds, int wcpu, int rcpu) {
+    return probe_line(bytes, k - 1, rounds, 0, 0, 1, wcpu, &rcpu, rcpu >= 0 ? 1 : 0);
 }
 
 /* ------------------------------------------------------------------ main */
 int main(int argc, char **argv) {
     signal(SIGPIPE, SIG_IGN);
     if (argc >= 4 && !strcmp(argv[1], "--probe-write")) return probe_write(atoi(argv[2]), atol(argv[3]));
+    if (argc >= 5 && !strcmp(argv[1], "--probe-line")) {
+        /* --probe-line BYTES RECIPIENTS ROUNDS [selread=0|1] [open=0|1] [readers] [wcpu] [rcpu,rcpu,...] */
+        int rc[PROBE_MAX_READERS], nrc = 0;
+        if (argc > 9) { char *p = argv[9], *tok; while ((tok = strsep(&p, ",")) && nrc < PROBE_MAX_READERS) if (*tok) rc[nrc++] = atoi(tok); }
+        return probe_line(atoi(argv[2]), atoi(argv[3]), atol(argv[4]), argc > 5 ? atoi(argv[5]) : 1, argc > 6 ? atoi(argv[6]) : 0,
+                          argc > 7 ? atoi(argv[7]) : 2, argc > 8 ? atoi(argv[8]) : -1, rc, nrc);
+    }
     if (argc >= 5 && !strcmp(argv[1], "--probe-fanout"))
         return probe_fanout(atoi(argv[2]), atoi(argv[3]), atol(argv[4]), argc > 5 ? atoi(argv[5]) : -1, argc > 6 ? atoi(argv[6]) : -1);
     FILE *fp = stdin;
@@ -645,7 +743,7 @@ int main(int argc, char **argv) {
         usleep(2000);
     }
     uint64_t t_login1 = now_ns();
-    struct cpu_sample s0[MAX_SERVERS], s1[MAX_SERVERS];
+    struct cpu_sample s0[MAX_SERVERS], s1[MAX_SERVERS], s2[MAX_SERVERS];
     uint64_t t0 = 0, t1 = 0; int timed_out = 0;
     double warm_s = 0.0;
     if (!atomic_load(&g_fail) && g_expect_warm) {
@@ -699,6 +797,13 @@ int main(int argc, char **argv) {
         for (int i = 0; i < g_nservers; i++) sample_pid(g_server_pids[i], &s1[i]);
         /* grace: anything beyond the expected count is an error worth seeing */
         if (!timed_out) usleep(50000);
+        /* system-call COUNTS are read after the grace period: the talker may still owe a write that no client
+           waits for (the PRM frame that follows a remote user's command, nuts333.c:2181), and with every sender
+           finished nothing else can add to them.  CPU time stays as sampled at the end of the timed window. */
+        for (int i = 0; i < g_nservers; i++) {
+            sample_pid(g_server_pids[i], &s2[i]);
+            s1[i].syscr = s2[i].syscr; s1[i].syscw = s2[i].syscw; s1[i].wchar = s2[i].wchar;
+        }
     }
     int failed = atomic_load(&g_fail);
     if (failed) {

@@ -87,20 +87,24 @@ class Talker:
         env = dict(os.environ, TZ=self.tz)
         out = open(self.root / "boot.log", "wb")
 
-        def _pre():
-            os.setsid()
+        # No preexec_fn (unsafe when the parent has threads, e.g. after torch was imported): the new session comes
+        # from start_new_session, and the CPU pin is inherited -- the calling thread narrows its own affinity
+        # around the fork and restores it.  The daemon the launcher forks (nuts333.c:79) inherits it in turn.
+        burn = [os.open(os.devnull, os.O_RDONLY) for _ in range(self.burn_fds)]
+        saved_affinity = None
+        try:
             if self.cpu is not None:
                 try:
+                    saved_affinity = os.sched_getaffinity(0)
                     os.sched_setaffinity(0, {self.cpu})
                 except OSError:
-                    pass
-
-        burn = [os.open(os.devnull, os.O_RDONLY) for _ in range(self.burn_fds)]
-        try:
+                    saved_affinity = None
             launcher = subprocess.Popen([self.binary.name[:30], self.config_name], executable=str(self.binary),
                                         cwd=self.root, stdin=subprocess.DEVNULL, pass_fds=burn,
-                                        stdout=out, stderr=subprocess.STDOUT, env=env, preexec_fn=_pre)
+                                        stdout=out, stderr=subprocess.STDOUT, env=env, start_new_session=True)
         finally:
+            if saved_affinity is not None:
+                os.sched_setaffinity(0, saved_affinity)
             out.close()
             for fd in burn:
                 os.close(fd)

@@ -156,7 +156,7 @@ def run_spec(spec: Spec, talkers: Sequence[Talker], *, timeout_s: float = 600.0,
     if proc.returncode != 0 or not res.get("ok"):
         raise RuntimeError(f"loadgen failed (rc={proc.returncode}): {err} {res}")
     res["expected_deliveries"] = spec.expected_deliveries
-    res["per_client_exact"] = res.pop("per_client_lines") == spec.expected_per_client
+    res["per_client_exact"] = res["per_client_lines"] == spec.expected_per_client
     res["exact"] = bool(res["per_client_exact"] and res["lines_total"] == spec.expect_lines
                         and res["deliveries"] == spec.expected_deliveries)
     return summarise(res)
@@ -205,6 +205,7 @@ def _run_single(build: Callable[[Spec, int], None], accounts, *, binary: Path, p
         spec = Spec()
         build(spec, ports[0])
         res = run_spec(spec, [talker], timeout_s=timeout_s, pin=pin)
+        res.pop("per_client_lines", None)
         res["server_rss_peak_kb"] = talker.rss_peak_kb()
         res["server_alive_after"] = talker.alive()
         return res
@@ -247,7 +248,7 @@ def config2(lines: int = 20_000, n: int = 10, *, colour: int = 0, all_send: bool
     return res
 
 
-def config3(per_client: int = 200, n: int = 100, *, seed: int = 333, six_rooms: bool = False, binary: Path,
+def config3(per_client: int = 200, n: int = 100, *, seed: int = 333, six_rooms: bool = False, warmup: int = 0, binary: Path,
             pin: bool = True, workdir=None, timeout_s: float = 600.0) -> dict:
     """n clients spread evenly over the rooms (5 as shipped, or 6 with the ``shop``); seeded 70/20/10
     say/.shout/.tell mix from every client."""
@@ -263,18 +264,19 @@ def config3(per_client: int = 200, n: int = 100, *, seed: int = 333, six_rooms: 
             for hop in pv.WALKS[room_of[i]]:
                 spec.add_pre(i, f".go {hop}")
         members = {r: [i for i in ids if room_of[i] == r] for r in rooms}
-        seq = 0
-        for _ in range(per_client):
+        # ``warmup`` untimed rounds first, drawn from their own generator so that the timed schedule (and with it
+        # the expected delivery count) is the same with and without a warm-up
+        for rnd, gen in [(-1 - k, random.Random(seed + 1 + k)) for k in range(warmup)] + [(k, rng) for k in range(per_client)]:
             for s in ids:
-                x = rng.random()
-                text = payload(seq); seq += 1
+                x = gen.random()
+                text = payload((rnd % 10_000) * n + s)
                 if x < 0.70:
-                    spec.add_line(s, text, [r for r in members[room_of[s]] if r != s])
+                    spec.add_line(s, text, [r for r in members[room_of[s]] if r != s], warm=rnd < 0)
                 elif x < 0.90:
-                    spec.add_line(s, ".shout " + text, [r for r in ids if r != s])
+                    spec.add_line(s, ".shout " + text, [r for r in ids if r != s], warm=rnd < 0)
                 else:
-                    tgt = rng.choice([r for r in ids if r != s])
-                    spec.add_line(s, f".tell {pv.bot_name(tgt)} {text}", [tgt])
+                    tgt = gen.choice([r for r in ids if r != s])
+                    spec.add_line(s, f".tell {pv.bot_name(tgt)} {text}", [tgt], warm=rnd < 0)
 
     res = _run_single(build, accounts, binary=binary, pin=pin, workdir=workdir, timeout_s=timeout_s, max_users=n + 10,
                       rooms=room_set)
@@ -297,15 +299,25 @@ def config4(lines: int = 1000, n: int = 1000, *, colour: int = 0, warmup: int = 
     return res
 
 
-def config5(lines: int = 1000, locals_each: int = 10, travellers: int = 5, *, binary: Path, pin: bool = True,
-            workdir=None, timeout_s: float = 300.0) -> dict:
-    """Two talkers joined by a netlink; a remote and a local user of talker2 shout concurrently."""
+def config5(lines: int = 1000, locals_each: int = 10, travellers: int = 5, *, warmup: int = 0, tap: bool = False,
+            binary: Path, pin: bool = True, workdir=None, timeout_s: float = 300.0) -> dict:
+    """Two talkers joined by a netlink; a remote and a local user of talker2 shout concurrently.
+
+    Frames on the link are MEASURED, two independent ways (nuts333.c:1302-1305, 3801, 2181):
+    * always: each talker's write(2) count from /proc/<pid>/io minus the lines its own clients received
+      = writes that went to the link socket (one per frame: write_sock, nuts333.c:1281-1286);
+    * with ``tap=True``: a counting relay on the link (``linktap.LinkTap``) that parses both byte streams and
+      counts frames by verb, the timed ones recognised by the payload phrase.  Not used in timed runs.
+    """
+    from .linktap import LinkTap
     tmp = Path(tempfile.mkdtemp(prefix="nuts333_nl_", dir=workdir))
-    t1 = t2 = None
+    t1 = t2 = link = None
     try:
         p1, p2 = free_ports(3), free_ports(3)
         names1 = [pv.bot_name(i) for i in range(locals_each)]
         names2 = [pv.bot_name(locals_each + i) for i in range(locals_each)]
+        if tap:
+            link = LinkTap(p2[2], marker=b"synthetic broadcast line")
         # talker2 accepts in its lounge (ACCEPT room); it must know talker1's site string as
         # reverse-resolved by gethostbyaddr (nuts333.c:322, 2908-2909): list both spellings
         cfg2 = pv.TalkerConfig(mainport=p2[0], wizport=p2[1], linkport=p2[2], verification="fred123x",
@@ -316,7 +328,7 @@ def config5(lines: int = 1000, locals_each: int = 10, travellers: int = 5, *, bi
                                r.description) for r in pv.DEFAULT_ROOMS)
         cfg1 = pv.TalkerConfig(mainport=p1[0], wizport=p1[1], linkport=p1[2], verification="bloggs456x",
                                auto_connect=True, rooms=rooms1,
-                               sites=[pv.Site("talker2", "127.0.0.1", p2[2], "fred123x")])
+                               sites=[pv.Site("talker2", "127.0.0.1", link.port if link else p2[2], "fred123x")])
         t2 = _boot(tmp / "t2", cfg2, [pv.Account(n) for n in names2], binary, _server_cpu(pin, 0))
         t1 = _boot(tmp / "t1", cfg1, [pv.Account(n) for n in names1], binary, _server_cpu(pin, 1))
         t1.wait_syslog("Connection to talker2 verified")
@@ -328,21 +340,39 @@ def config5(lines: int = 1000, locals_each: int = 10, travellers: int = 5, *, bi
             spec.add_pre(i, ".go talker2")        # TRANS -> GRANTED -> ACT look -> MSG frames back
         on_t2 = ids2 + gone
         remote_sender, local_sender = gone[0], ids2[0]
-        for k in range(lines):
+        for k in range(-warmup, lines):
             for s in (remote_sender, local_sender):
-                spec.add_line(s, ".shout " + payload(k), [r for r in on_t2 if r != s])
+                spec.add_line(s, ".shout " + payload(k % 1_000_000), [r for r in on_t2 if r != s], warm=k < 0)
         res = run_spec(spec, [t1, t2], timeout_s=timeout_s, pin=pin, threads=2)
         res["workload"] = (f"config5: 2 talkers, {locals_each} locals each, {travellers} of talker1's users on talker2, "
                            f"1 remote + 1 local sender x {lines} shouts")
-        # every line that reaches a travelling user crossed the link as one MSG..EMSG frame (nuts333.c:1302-1305)
-        res["netlink_frames_t2_to_t1"] = (2 * lines) * (len(gone) - 1) + lines + lines   # deliveries + remote sender's acks
-        res["netlink_frames_t1_to_t2"] = lines                                            # ACT <name> .shout ...
+        # measured: write(2) calls of each talker that did NOT end in one of its own clients' sockets went to the link
+        per_client = res.pop("per_client_lines")
+        rx1, rx2 = sum(per_client[i] for i in ids1), sum(per_client[i] for i in ids2)
+        s1, s2 = res["servers"]
+        res["netlink"] = {
+            "method": "/proc/<pid>/io write(2) count of each talker minus the lines its own clients received",
+            "writes_t1_to_t2": s1["write_syscalls"] - rx1,        # ACT <name> .shout ...        (nuts333.c:3801)
+            "writes_t2_to_t1": s2["write_syscalls"] - rx2,        # MSG..EMSG frames + PRM <name>  (c:1302-1305, 2181)
+            # what the protocol says those must be: every line that reaches a travelling user crossed the link as ONE
+            # MSG..EMSG frame; every relayed command is ONE ACT frame and is answered by ONE PRM frame
+            "expected_act_frames": lines,
+            "expected_msg_frames": 2 * lines * (len(gone) - 1) + 2 * lines,
+            "expected_prm_frames": lines,
+        }
+        res["netlink"]["exact"] = (res["netlink"]["writes_t1_to_t2"] == res["netlink"]["expected_act_frames"] and
+                                   res["netlink"]["writes_t2_to_t1"] == res["netlink"]["expected_msg_frames"]
+                                   + res["netlink"]["expected_prm_frames"])
+        if link:
+            res["netlink"]["tap"] = link.snapshot()
         res["servers_alive_after"] = [t1.alive(), t2.alive()]
         return res
     finally:
         for t in (t1, t2):
             if t is not None:
                 t.stop()
+        if link:
+            link.close()
         shutil.rmtree(tmp, ignore_errors=True)
 
 

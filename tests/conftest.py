@@ -17,6 +17,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "reference: needs oracle/_ref/nuts333 (built where /root/reference exists)")
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Two tiers from one test body.  The driver runs `-m "not gpu"` here and `-m gpu` on the MI355X box; a marker
+# expression cannot select the same item for both, so modules that set ``BOTH_TIERS = True`` get every test
+# parametrised over ``tier``: the "host" instance is unmarked, the "gpubox" instance carries the gpu marker.  This
+# is how the real parity suite (all golden sessions, the transducer vectors) runs on the box's host as well.
+@pytest.fixture(autouse=True)
+def tier(request):
+    return getattr(request, "param", "host")
+
+
+def pytest_generate_tests(metafunc):
+    if getattr(metafunc.module, "BOTH_TIERS", False):
+        metafunc.parametrize("tier", [pytest.param("host"), pytest.param("gpubox", marks=pytest.mark.gpu)], indirect=True)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def built():
     """Compile the restatement and the load generator (seconds; gcc only)."""

@@ -187,10 +187,39 @@ def test_config4_shout_fan_out(port_binary):
 
 
 def test_config5_two_talkers_over_a_netlink(port_binary):
-    res = workloads.config5(lines=30, binary=port_binary)
+    res = workloads.config5(lines=30, warmup=3, binary=port_binary)
     _check(res)
     assert res["deliveries"] == 2 * 30 * 14 and len(res["servers"]) == 2
-    assert res["netlink_frames_t2_to_t1"] == 300
+    _check_link_frames(res, lines=30, travellers=5)
+
+
+def _check_link_frames(res, lines, travellers):
+    """MEASURED link traffic (write(2) counts of each talker that did not go to one of its own clients) against
+    what the protocol prescribes: one ACT frame per relayed command (nuts333.c:3801), one MSG..EMSG frame per
+    line that reaches a travelling user (c:1302-1305), one PRM frame per relayed command (c:2181)."""
+    nl = res["netlink"]
+    assert nl["writes_t1_to_t2"] == lines
+    assert nl["writes_t2_to_t1"] == (2 * lines * (travellers - 1) + 2 * lines) + lines
+    assert nl["exact"]
+
+
+@pytest.mark.parametrize("impl", ["port", "reference"])
+def test_config5_link_frames_counted_on_the_wire(impl, port_binary, request):
+    """The same count taken a second, independent way: a relay on the link parses both byte streams and counts
+    frames by verb; the timed frames are told apart by the payload phrase.  Both methods and the formula agree."""
+    binary = port_binary if impl == "port" else request.getfixturevalue("ref_binary")
+    lines, travellers = 25, 4
+    res = workloads.config5(lines=lines, travellers=travellers, tap=True, binary=binary)
+    _check(res)
+    _check_link_frames(res, lines, travellers)
+    tap = res["netlink"]["tap"]
+    assert tap["marked_dial_to_accept"] == {"ACT": lines}
+    assert tap["marked_accept_to_dial"] == {"MSG": 2 * lines * (travellers - 1) + 2 * lines}
+    # whole session: every MSG is closed by an EMSG; one PRM per relayed command -- the timed shouts plus each
+    # traveller's arrival `look` (nuts333.c:3218-3224); one TRANS and one GRANTED per traveller plus GRANTED CONNECT
+    assert tap["accept_to_dial"]["MSG"] == tap["accept_to_dial"]["EMSG"]
+    assert tap["accept_to_dial"]["PRM"] == lines + travellers == tap["dial_to_accept"]["ACT"]
+    assert tap["dial_to_accept"]["TRANS"] == travellers and tap["accept_to_dial"]["GRANTED"] == travellers + 1
 
 
 def _syscalls(res):
@@ -230,7 +259,9 @@ def test_small_workloads_against_the_reference(ref_binary):
     _check(workloads.config2(lines=300, warmup=30, binary=ref_binary), "config2")
     _check(workloads.config3(per_client=10, n=25, binary=ref_binary), "config3")
     _check(workloads.config4(lines=20, n=120, binary=ref_binary), "config4")
-    _check(workloads.config5(lines=30, binary=ref_binary), "config5")
+    r5 = workloads.config5(lines=30, binary=ref_binary)
+    _check(r5, "config5")
+    _check_link_frames(r5, lines=30, travellers=5)
 
 
 def test_loadgen_reports_a_rejected_login(tmp_path, port_binary):
@@ -249,7 +280,22 @@ def test_write_probes_produce_numbers(built):
     p = workloads.probe_write(67, 20000)
     assert p["cpu_ns_per_write"] > 0
     out = subprocess.run([str(workloads.LOADGEN_BIN), "--probe-fanout", "67", "9", "500"], check=True, stdout=subprocess.PIPE).stdout
-    assert json.loads(out)["writes_per_s"] > 0
+    j = json.loads(out)
+    assert j["written_lines_per_s_cpu"] > 0 and j["writes_per_line"] == 9 and j["select_read"] == 0 and j["bytes_ok"]
+
+
+@pytest.mark.parametrize("open_loop", [0, 1])
+def test_line_probe_does_the_per_input_line_system_calls(built, open_loop):
+    """--probe-line: 1 select(FD_SETSIZE) + 1 read + (recipients+1) writes per round; every byte
+    written must arrive; the select+read share is reported on its own."""
+    out = subprocess.run([str(workloads.LOADGEN_BIN), "--probe-line", "69", "49", "400", "1", str(open_loop), "2"],
+                         check=True, stdout=subprocess.PIPE).stdout
+    j = json.loads(out)
+    assert j["mode"] == ("open" if open_loop else "closed") and j["select_read"] == 1 and j["select_nfds"] == 1024
+    assert j["writes_per_line"] == 50 and j["recipients"] == 49 and j["bytes_ok"] is True
+    assert 0 < j["cpu_ns_select_read_per_line"] < j["cpu_ns_per_line"]
+    # the two shares add up (values are printed to 0.1 ns, so allow 50 x 0.05 of rounding)
+    assert abs(j["cpu_ns_per_line"] - (j["cpu_ns_select_read_per_line"] + 50 * j["cpu_ns_per_write"])) < 5.0
 
 
 # ---------------------------------------------------------------- bench.py contract
@@ -265,14 +311,35 @@ def _bench(*args, env=None):
 
 
 def test_bench_single_replica_contract():
-    j = _bench("--steps", "2", "--warmup", "1", "--lines-per-step", "200", "--binary", "port")
+    j = _bench("--steps", "2", "--warmup", "1", "--lines-per-step", "200", "--binary", "port", "--workload", "config2")
     assert CONTRACT_KEYS <= set(j)
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["gpu_used"] is False
     assert j["delivered"] == j["expected_delivered"] == 2 * 200 * 9
     assert j["vs_baseline"] is None and j["scaling"] == "weak" and j["higher_is_better"] is True
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1
-    assert j["roofline"]["bound"] == "host-syscall" and 0 < j["roofline"]["frac"] < 2 and j["roofline"]["traffic"] is None
+    r = j["roofline"]
+    assert r["bound"] == "host-syscall" and 0 < r["frac"] < 2 and r["traffic"] is None
+    # the ceiling counts what SURVEY.md 8(d) says one input line costs: 1 select + 1 read + (9 + 1) writes
+    assert r["per_input_line"] == {**r["per_input_line"], "select": 1, "read": 1, "write": 10, "select_nfds": 1024}
+    assert set(r["probe"]) == {"write_only_closed", "full_closed", "full_open"}
+    assert r["peak"] == min(r["peak_closed_loop_cpu_time"], r["peak_open_loop_wall_demonstrated"])
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak_write_only"] > 0
+    assert all(leg["bytes_ok"] for leg in r["probe"].values())
     assert "model" not in j["config"] and "workload" in j["config"]
+    # every BASELINE configuration is in the same line, exact, with measured link frames for #5
+    names = [c["name"] for c in j["configs"]]
+    assert names == ["config1", "config2", "config3", "config4", "config5"] and j["configs_all_exact"]
+    assert [c["n"] for c in j["configs"]] == [1, 10, 100, 1000, 20]
+    assert j["configs"][4]["netlink"]["writes_t2_to_t1"] == 11000 and j["configs"][4]["netlink"]["writes_t1_to_t2"] == 1000
+
+
+def test_bench_default_headline_is_the_largest_configuration():
+    """Driver default: BASELINE configs[3] -- 1000 clients, .shout.  Headline leg only here."""
+    j = _bench("--steps", "2", "--warmup", "1", "--binary", "port", "--no-extras")
+    assert j["config"]["baseline_config"] == "config4" and j["config"]["clients"] == 1000
+    assert j["config"]["lines_per_step"] == 100 and j["delivered"] == j["expected_delivered"] == 2 * 100 * 999
+    assert j["server_syscalls"]["per_input_line"] == {"read": 1.0, "write": 1000.0}
+    assert j["roofline"] is None and "configs" not in j
 
 
 def test_bench_two_replicas_gloo():
@@ -280,15 +347,34 @@ def test_bench_two_replicas_gloo():
     port = free_ports(1)[0]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(REPO / "bench.py"),
-                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--lines-per-step", "200", "--binary", "port"],
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--lines-per-step", "10", "--binary", "port"],
                          check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600).stdout.decode()
     lines = [l for l in out.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["delivered"] == j["expected_delivered"] == 2 * (2 * 200 * 9)
+    assert j["config"]["baseline_config"] == "config4"
+    assert j["n_gpus"] == 2 and j["delivered"] == j["expected_delivered"] == 2 * (2 * 10 * 999)
     assert j["roofline"] is None            # probes run at N=1 only
 
 
 def test_bench_self_launch_of_replicas():
-    j = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--lines-per-step", "200", "--binary", "port")
+    j = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--lines-per-step", "200", "--binary", "port", "--workload", "config2")
     assert j["n_gpus"] == 2 and j["delivered"] == 2 * 200 * 9
+
+
+def test_bench_failed_replica_ends_the_job_instead_of_hanging(tmp_path):
+    """a rank whose run fails must take the others down through the first collective, not leave them in
+    gloo until its 30-minute timeout.  Rank 1 is given a load generator that cannot run."""
+    port = free_ports(1)[0]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if r == 1:
+            env["NUTS_BENCH_INJECT_FAILURE"] = "1"
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                                       "--lines-per-step", "50", "--binary", "port", "--workload", "config2"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert [p.returncode for p in procs] == [1, 1]
+    assert b"injected failure" in outs[1][1] and b"another replica failed" in outs[0][1]
+    assert not outs[0][0].strip()            # no result line from a job that did not complete

@@ -9,6 +9,8 @@ Expected values come from the reference, not from reading our own code back:
 """
 from __future__ import annotations
 
+BOTH_TIERS = True       # tests/conftest.py: every test here also runs in the gpu tier, on the MI355X box's host
+
 import ctypes
 import json
 import re

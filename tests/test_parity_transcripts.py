@@ -10,6 +10,8 @@ conformance check of the wire protocol available.
 """
 from __future__ import annotations
 
+BOTH_TIERS = True       # tests/conftest.py: every test here also runs in the gpu tier, on the MI355X box's host
+
 import json
 from pathlib import Path
 
