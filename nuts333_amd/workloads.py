@@ -87,6 +87,7 @@ class Spec:
         self.expect_warm_lines = 0
         self.expect_lines = 0
         self.expected_deliveries = 0
+        self.expected_self_extra = 0          # lines a sender gets besides its ack (its prompt line): not deliveries
         self.expected_per_client: list[int] = []
 
     def add_client(self, name: str, port: int, host: str = "127.0.0.1", password: str = pv.PASSWORD) -> int:
@@ -97,21 +98,24 @@ class Spec:
     def add_pre(self, idx: int, line: str, expect: str = LOOK_END) -> None:
         self.pre.append((idx, expect, line))
 
-    def add_line(self, sender: int, text: str, recipients: Sequence[int], warm: bool = False) -> None:
+    def add_line(self, sender: int, text: str, recipients: Sequence[int], warm: bool = False, self_lines: int = 1) -> None:
         """One input line; ``recipients`` are the client indices that must receive one line each.
-        ``warm`` lines run in an untimed phase before the timed one."""
+        ``warm`` lines run in an untimed phase before the timed one.  ``self_lines`` is what the sender itself
+        gets back per input line: 1 = the acknowledgement ("You say: ..."); 2 when the account has its prompt on
+        (one more write_user from prompt(), nuts333.c:2174-2197)."""
         assert "\n" not in text and "\t" not in text and len(text) < 900
         if warm:
             self.warm.append((sender, text))
-            self.expect_warm_lines += 1 + len(recipients)
+            self.expect_warm_lines += self_lines + len(recipients)
             return
         self.lines.append((sender, text))
-        self.expected_per_client[sender] += 1          # the acknowledgement
+        self.expected_per_client[sender] += self_lines   # the acknowledgement (+ the prompt)
         for r in recipients:
             assert r != sender
             self.expected_per_client[r] += 1
-        self.expect_lines += 1 + len(recipients)
+        self.expect_lines += self_lines + len(recipients)
         self.expected_deliveries += len(recipients)
+        self.expected_self_extra += self_lines - 1
 
     def render(self, server_pids: Sequence[int], threads: int, cpus: Sequence[int], timeout_s: float,
                login_window: int, spin: bool = True, quickack: bool = True, drain_quiet_ms: int = 40) -> str:
@@ -156,6 +160,8 @@ def run_spec(spec: Spec, talkers: Sequence[Talker], *, timeout_s: float = 600.0,
     if proc.returncode != 0 or not res.get("ok"):
         raise RuntimeError(f"loadgen failed (rc={proc.returncode}): {err} {res}")
     res["expected_deliveries"] = spec.expected_deliveries
+    res["deliveries"] -= spec.expected_self_extra        # the load generator counts "lines that are not acks"
+    res["self_extra_lines"] = spec.expected_self_extra
     res["per_client_exact"] = res["per_client_lines"] == spec.expected_per_client
     res["exact"] = bool(res["per_client_exact"] and res["lines_total"] == spec.expect_lines
                         and res["deliveries"] == spec.expected_deliveries)
@@ -215,15 +221,17 @@ def _run_single(build: Callable[[Spec, int], None], accounts, *, binary: Path, p
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def config1(lines: int = 10_000, *, warmup: int = 0, binary: Path, pin: bool = True, workdir=None, timeout_s: float = 300.0) -> dict:
-    """1 client, ``.go lounge``, closed-loop say; nobody else hears it (plumbing / latency)."""
-    accounts = [pv.Account("Fred", level=4, desc="the GOD account")]
+def config1(lines: int = 10_000, *, warmup: int = 0, prompt: int = 0, binary: Path, pin: bool = True, workdir=None,
+            timeout_s: float = 300.0) -> dict:
+    """1 client, ``.go lounge``, closed-loop say; nobody else hears it (plumbing / latency).  ``prompt=1`` gives the
+    account the flags of the shipped ``userfiles/Fred.D`` (prompt on, character echo on): two writes per input line."""
+    accounts = [pv.Account("Fred", level=4, desc="the GOD account", prompt=prompt, charmode_echo=prompt)]
 
     def build(spec: Spec, port: int) -> None:
         c = spec.add_client("Fred", port)
         spec.add_pre(c, ".go lounge")          # GOD teleports (nuts333.c:4399-4404)
         for i in range(-warmup, lines):
-            spec.add_line(c, payload(i % 1_000_000), [], warm=i < 0)
+            spec.add_line(c, payload(i % 1_000_000), [], warm=i < 0, self_lines=1 + prompt)
 
     res = _run_single(build, accounts, binary=binary, pin=pin, workdir=workdir, timeout_s=timeout_s)
     res["workload"] = f"config1: 1 client, {lines} say lines in lounge"
