@@ -28,7 +28,7 @@ What they pin, by reference function:
                 REMVD on the way home, offsite tell, home execution               3452-3479, 3787-3806, 4168-4172
   netlink_wire_* a scripted peer speaks the link protocol itself: every verb's    c:2892-2942, 2946-3073, 3077-3479,
                 bytes in both directions, split/merged segments, denials, link     3689-3746, 4305-4375
-                shutdown
+                shutdown; _legacy: what peers announcing 3.3.2 / 3.1.0 are sent    c:1299-1300, 3093-3097, 3129-3146
 """
 from __future__ import annotations
 
@@ -95,6 +95,10 @@ def speech_colour_mixed():
         s.line("c", ".tell bobby stripped for bobby")
         s.line("a", ";emotes")
         s.line("b", "#semotes")
+        s.line("b", ".pemote alice private emote to a colour user")
+        s.line("a", "< bobby private emote to a plain user")
+        s.line("b", "- an echo reaches colour users with resets")
+        s.line("c", ".echo ~FGgreen~RS echo, stripped for bobby")
         s.line("b", ".colour", colour=True)
         s.line("a", "now bobby has colour too")
         s.line("a", ".colour", colour=False)
@@ -292,11 +296,11 @@ def prompts():
 def afk_bcast():
     """The AFK branch of the main loop, and the two level-scoped fan-outs (nuts333.c:180-203, 4149-4155,
     4772-4788, 6527-6565, 7409-7454)."""
-    accounts = [_acc(A), _acc(B), _acc(C, level=2), _acc(D, level=3)]
+    accounts = [_acc(A), _acc(B), _acc(C, level=2, colour=1), _acc(D, level=3)]
 
     def script(s):
         for k, n in (("a", A), ("b", B), ("c", C), ("d", D)):
-            s.connect(k); s.login(k, n)
+            s.connect(k); s.login(k, n, colour=(k == "c"))    # Carol hears bcast / wizshout with colour on
         s.line("a", ".afk", can_sync=False)
         s.line("b", ".tell alice are you there")
         s.line("b", "< alice pokes")
@@ -646,6 +650,52 @@ def netlink_wire_dial():
             "wait_syslog": [(0, "Connected to peer2")], "script": script}
 
 
+def netlink_wire_legacy():
+    """Peers that announce an older protocol version get the older answers (nuts333.c:1299-1300, 3093-3097, 3129-3139,
+    3141-3146): a banned or locked-out traveller is DENIED 6 instead of 9 / 8, a pre-3.3.1 TRANS carries no level word
+    and the user gets rem_user_deflevel, a pre-3.2 peer is sent MSG bodies with the colour commands stripped.  Three
+    links in a row on the same talker: 3.3.2, 3.1.0, then 3.3.3 for the contrast."""
+    accounts = [_acc(B)]
+
+    def configs(p, peer_ports):
+        return [pv.TalkerConfig(mainport=p[0][0], wizport=p[0][1], linkport=p[0][2], max_users=50, verification="verify0",
+                                minlogin_level="USER", rem_user_deflevel="WIZ",
+                                sites=[pv.Site("peer1", "localhost", 1, "verify1"), pv.Site("peer1", "127.0.0.1", 1, "verify1")])]
+
+    def link_up(s, key, version):
+        s.peers[key].dial(s.link_ports[0])
+        s.peer_step(key, b"", b"GRANTED CONNECT\n")
+        s.peer_step(key, b"VERIFICATION verify1 " + version + b"\n", b"VERIFY OK ALL\n")
+
+    def script(s):
+        s.connect("b"); s.login("b", B)
+        for hop in pv.WALKS["lounge"]:
+            s.line("b", f".go {hop}")
+        link_up(s, "p", b"3.3.2")
+        s.peer_step("p", b"TRANS Mallory somehash 1 is banned here\n", b"DENIED Mallory 6\n", note="banned: the old code for an old peer")
+        s.peer_step("p", b"TRANS Newbie somehash 0 is below minlogin_level\n", b"DENIED Newbie 6\n", note="locked out: the old code too")
+        s.peer_step("p", b"TRANS Alice somehash 4 has a level word\n", b"GRANTED Alice\n", note="3.3.1+: level taken from the frame, capped")
+        s.peer_step("p", b"ACT Alice .wizshout capped at WIZ\n", b"PRM Alice\n")
+        s.line("b", "~FRcolour commands~RS cross a 3.3.2 link as they are"); s.peer_expect("p", b"EMSG\n")
+        s.peer_step("p", b"DISCONNECT\n", None, closes=True)
+        link_up(s, "q", b"3.1.0")
+        s.peer_step("q", b"TRANS Carol somehash the description starts at the third word\n", b"GRANTED Carol\n",
+                    note="pre-3.3.1: no level word; the user gets rem_user_deflevel")
+        s.peer_step("q", b"ACT Carol .wizshout deflevel is WIZ here\n", b"PRM Carol\n")
+        s.line("b", ".look", note="the description as the talker took it")
+        s.line("b", "~FRcolour commands~RS are stripped for a pre-3.2 peer, /~FR too"); s.peer_expect("q", b"EMSG\n")
+        s.peer_step("q", b"TRANS Mallory somehash banned\n", b"DENIED Mallory 6\n")
+        s.peer_step("q", b"DISCONNECT\n", None, closes=True)
+        link_up(s, "r", b"3.3.3")
+        s.peer_step("r", b"TRANS Mallory somehash 1 is banned here\n", b"DENIED Mallory 9\n", note="3.3.3 peers get the new codes")
+        s.peer_step("r", b"TRANS Newbie somehash 0 is below minlogin_level\n", b"DENIED Newbie 8\n")
+        s.peer_step("r", b"DISCONNECT\n", None, closes=True)
+        s.line("b", "all three links are gone")
+
+    return {"configs": configs, "accounts": [accounts], "boot_order": [0], "peers": ["p", "q", "r"], "script": script,
+            "files": {"datafiles/userban": "Mallory\n"}}
+
+
 SCENARIOS = {
     "speech_colour_off": speech_colour_off,
     "speech_colour_mixed": speech_colour_mixed,
@@ -665,4 +715,5 @@ SCENARIOS = {
     "netlink": netlink,
     "netlink_wire_accept": netlink_wire_accept,
     "netlink_wire_dial": netlink_wire_dial,
+    "netlink_wire_legacy": netlink_wire_legacy,
 }
