@@ -8,9 +8,10 @@ reply it has also seen every byte the step caused to be written to it.  The repl
 is cut off the capture.  No "quiet for N ms" heuristics -- with one exception: multi-segment
 ``raw`` steps pause between segments so the talker read()s each one on its own.
 
-Only two things in a transcript are not a pure function of (accounts, script):
-the peer ``(site:port)`` shown to WIZ+ on sign-on (``nuts333.c:1732``) and the wall clock
-in the prompt (``nuts333.c:2191-2195``); :func:`normalise` masks exactly those.
+Only three things in a transcript are not a pure function of (accounts, script):
+the peer ``(site:port)`` shown to WIZ+ on sign-on (``nuts333.c:1732``), the wall clock
+in the prompt (``nuts333.c:2191-2195``) and the date stamp on board messages and mail
+(``long_date(0)`` and the raw ``time_t`` beside it, ``nuts333.c:2614, 5025-5027, 2469, 2493-2496``); :func:`normalise` masks exactly those.
 """
 from __future__ import annotations
 
@@ -26,10 +27,17 @@ RESET = b"\x1b[0m"
 
 _SITE_PORT = re.compile(rb"\([A-Za-z0-9_.\-]+:\d{1,5}\)")
 _PROMPT = re.compile(rb"<\d\d:\d\d, \d\d:\d\d, ")
+# long_date(0), nuts333.c:2614-2623: the stamp on board messages and mail ("[ Sunday 4th October 2026 at 13:05 ]"-like)
+# a time_t followed by a bare CR: the machine-readable stamp in front of a board header ("PT: <time_t>\r", nuts333.c:5025)
+# and on the first line of a mail file (c:2469), both shown as they are by .read / .rmail; no other output has digits + CR
+_TIME_T_CR = re.compile(rb"(?<![0-9])\d{9,11}\r")
+_LONG_DATE = re.compile(rb"\[ [A-Z][a-z]+ \d{1,2} [A-Z][a-z]+ \d{4} at \d\d:\d\d \]")
 
 
 def normalise(b: bytes) -> bytes:
     b = _SITE_PORT.sub(b"(SITE:PORT)", b)
+    b = _LONG_DATE.sub(b"[ DATE ]", b)
+    b = _TIME_T_CR.sub(b"T\r", b)
     return _PROMPT.sub(b"<HH:MM, HH:MM, ", b)
 
 

@@ -27,7 +27,7 @@ from scenario_runner import run_scenario                    # noqa: E402
 
 
 def main(argv: list[str]) -> int:
-    names = argv or list(scenarios.SCENARIOS)
+    names = argv or list(scenarios.SCENARIOS) + list(scenarios.REFERENCE_ONLY)
     if not REF_BINARY.exists():
         print("oracle/_ref/nuts333 is missing: run `make -C oracle ref` first", file=sys.stderr)
         return 2
@@ -42,7 +42,8 @@ def main(argv: list[str]) -> int:
         if a != c:
             print(f"{name}: two runs of the same build disagree (nondeterministic capture)", file=sys.stderr)
             return 1
-        path = out_dir / f"{name}.json"
+        path = out_dir / ("reference_only" if name in scenarios.REFERENCE_ONLY else "") / f"{name}.json"
+        path.parent.mkdir(exist_ok=True)
         path.write_text(json.dumps(a, indent=1, ensure_ascii=True) + "\n")
         nbytes = sum(len(v) for s in a["steps"] for v in s["recv"].values())
         print(f"{name}: {len(a['steps'])} steps, {nbytes} received bytes -> {path.relative_to(REPO)}")

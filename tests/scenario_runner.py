@@ -21,7 +21,7 @@ import scenarios
 
 
 def run_scenario(name: str, binaries: Path | Sequence[Path]) -> dict:
-    spec = scenarios.SCENARIOS[name]()
+    spec = (scenarios.SCENARIOS.get(name) or scenarios.REFERENCE_ONLY[name])()
     if isinstance(spec, tuple):
         cfg_kw, accounts, script = spec
         spec = {
@@ -64,7 +64,7 @@ def run_scenario(name: str, binaries: Path | Sequence[Path]) -> dict:
                 while not path.exists() and __import__("time").monotonic() < deadline:
                     __import__("time").sleep(0.02)
                 __import__("time").sleep(0.1)
-                files[rel] = scenarios.mask_user_record(path.read_text()) if path.exists() else None
+                files[rel] = scenarios.mask_file(rel, path.read_bytes().decode("latin-1")) if path.exists() else None
         finally:
             sess.shutdown()
             for t in talkers:

@@ -46,6 +46,26 @@ def mask_user_record(text: str) -> str:
     return "\n".join(lines)
 
 
+_PT = __import__("re").compile(r"PT: \d+\r")
+_LONG_DATE = __import__("re").compile(r"\[ [A-Z][a-z]+ \d{1,2} [A-Z][a-z]+ \d{4} at \d\d:\d\d \]")
+
+
+def mask_file(rel: str, text: str) -> str:
+    """On-disk side effects with their wall-clock fields masked, by file type:
+    ``.D`` user record (four timestamps on line 2, DOCS/userdata_format:7-15);
+    ``.B`` board: ``PT: <time_t>\\r`` in front of each header and the date stamp in it (nuts333.c:5020-5028);
+    ``.M`` mail: ``<time_t>\\r`` opening the file (nuts333.c:2468-2469) and the date stamp of each header (c:2493-2496)."""
+    if rel.endswith(".D"):
+        return mask_user_record(text)
+    text = _LONG_DATE.sub("[ DATE ]", text)
+    if rel.endswith(".B"):
+        return _PT.sub("PT: T\r", text)
+    if rel.endswith(".M"):
+        head, sep, rest = text.partition("\r")
+        return ("T" if head.isdigit() else head) + sep + rest
+    return text
+
+
 def _acc(name, **kw):
     return pv.Account(name, **{"desc": f"is {name.lower()}", **kw})
 
@@ -695,6 +715,34 @@ def netlink_wire_legacy():
     return {"configs": configs, "accounts": [accounts], "boot_order": [0], "peers": ["p", "q", "r"], "script": script,
             "files": {"datafiles/userban": "Mallory\n"}}
 
+
+def board_mail_files():
+    """REFERENCE ONLY (the restatement answers board and mail commands with a notice): the two
+    remaining on-disk formats of SURVEY.md 8(f)4 -- board ``.B`` (``PT:`` header, 80-column wrap, nuts333.c:5008-5040)
+    and mail ``.M`` (time stamp on the first line, older mail kept below it, nuts333.c:2462-2503)."""
+    accounts = [_acc(A), _acc(B), _acc(D, level=3)]
+
+    def script(s):
+        for k, n in (("a", A), ("b", B), ("d", D)):
+            s.connect(k); s.login(k, n)
+        s.line("a", ".write first message on the board")
+        s.line("b", ".write a second one ~FRwith a colour command~RS kept as typed")
+        s.line("a", ".write " + "w" * 170, note="the body is wrapped after 80 characters")
+        s.line("d", ".invis")
+        s.line("d", ".write from a presence", note="an invisible writer is not named")
+        s.line("a", ".read")
+        s.line("a", ".smail bobby hello by mail")
+        s.line("d", ".smail bobby a second mail: the new stamp goes on top, the old mail stays")
+        s.line("b", ".rmail")
+        s.line("a", ".smail nobody no such user")
+
+    return {"configs": lambda p: [pv.TalkerConfig(mainport=p[0][0], wizport=p[0][1], linkport=p[0][2], max_users=50)],
+            "accounts": [accounts], "boot_order": [0], "script": script,
+            "collect_files": ["datafiles/drive.B", "userfiles/Bobby.M"]}
+
+
+#: scenarios only the reference can run; fixtures under tests/golden/reference_only/
+REFERENCE_ONLY = {"board_mail_files": board_mail_files}
 
 SCENARIOS = {
     "speech_colour_off": speech_colour_off,

@@ -81,9 +81,39 @@ def test_netlink_interop_with_reference(order, port_binary, ref_binary):
     assert got == gold, _diff(gold, got)
 
 
+@pytest.mark.reference
+@pytest.mark.parametrize("name", list(scenarios.REFERENCE_ONLY))
+def test_reference_only_fixture(name, ref_binary):
+    """SURVEY.md 8(f)4 remainder: board ``.B`` and mail ``.M`` files as the reference writes them.  The restatement
+    does not implement boards or mail, so this is checked against the reference build only."""
+    gold = json.loads((GOLDEN / "reference_only" / f"{name}.json").read_text())
+    got = run_scenario(name, ref_binary)
+    assert got["steps"] == gold["steps"], _diff(gold["steps"], got["steps"])
+    assert got["files"] == gold["files"]
+
+
+def test_board_and_mail_file_formats_in_the_fixture():
+    """The formats themselves, read off the committed fixture (nuts333.c:5020-5040, 2462-2503; DOCS/about_dirs:25-30)."""
+    files = json.loads((GOLDEN / "reference_only" / "board_mail_files.json").read_text())["files"]
+    board = files["datafiles/drive.B"]
+    posts = board.split("PT: T\r")[1:]                       # machine-readable posting time, then CR, then the header
+    assert len(posts) == 4 and board.startswith("PT: T\r")
+    for post, who in zip(posts, ("Alice", "Bobby", "Alice", "A presence")):
+        head, _, body = post.partition("\n")
+        assert head == f"~OLFrom: {who}  [ DATE ]"
+        assert body.endswith("\n\n") and all(len(l) <= 80 for l in body.split("\n"))     # wrapped at 80 columns
+    assert "w" * 80 + "\n" + "w" * 80 + "\n" + "w" * 10 + "\n\n" in posts[2]
+    assert "~FRwith a colour command~RS" in posts[1]          # stored as typed; expanded when read
+    mail = files["userfiles/Bobby.M"]
+    stamp, _, rest = mail.partition("\r")
+    assert stamp == "T"                                       # first line: time of the newest mail (has_unread_mail, c:2426-2438)
+    assert rest.lstrip("\r") == ("~OLFrom: Alice  [ DATE ]\nhello by mail\n\n"
+                                  "~OLFrom: Dave  [ DATE ]\na second mail: the new stamp goes on top, the old mail stays\n\n")
+
+
 def test_fixtures_contain_no_reference_source():
     """A fixture is data: provisioning, inputs, received bytes -- nothing else."""
-    for p in GOLDEN.glob("*.json"):
+    for p in list(GOLDEN.glob("*.json")) + list((GOLDEN / "reference_only").glob("*.json")):
         d = json.loads(p.read_text())
         assert set(d) <= {"scenario", "config", "accounts", "steps", "files"}
         for st in d["steps"]:
