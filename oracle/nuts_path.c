@@ -1,10 +1,12 @@
 /*
  * nuts_path.c -- CPU restatement of the NUTS 3.3.3 input -> broadcast path (pure functions).
  *
- * TEST INFRASTRUCTURE / ORACLE -- see nuts_path.h.  Written from the behaviour of the
- * reference, not from its text: own data layout, own control flow, bounded buffers.  Where
- * the reference has an observable quirk the quirk is kept and called out, because the
- * golden transcripts (captured from the real thing) contain it.
+ * TEST INFRASTRUCTURE / ORACLE -- see nuts_path.h.  Restated function by function from the
+ * lines of the reference each one cites (file:line in the comment above it), with our own
+ * data layout, re-entrant signatures and bounded buffers; the control flow of the byte
+ * transducer (np_stage_feed) is our own arrangement of the reference's rules.  Where the
+ * reference has an observable quirk the quirk is kept and called out, because the golden
+ * transcripts (captured from the real thing) contain it.
  */
 #include "nuts_path.h"
 
@@ -126,10 +128,17 @@ static int colcom_at(const char *p)
  * staged through a 1000-byte buffer that is flushed (= one write(2)) when it is full, or
  * before a newline / tilde once fewer than 6 bytes remain; a trailing ESC[0m goes out as a
  * separate write when colour is on. */
-void np_write_user_stream(const char *str, int colour, np_emit_fn emit, void *ctx)
+void np_stage_init(struct np_stage *st) { st->pos = 0; }
+
+/* One string through the staging buffer WITHOUT the final flush: what is left stays staged for the next
+ * call.  write_user (below) stages one string and flushes; the file pager more() stages every line of a
+ * file through the same buffer and flushes once at the end (nuts333.c:2250-2296), so its write(2)
+ * boundaries fall where the running position says, not per line.  The "/~" look-behind is per string in
+ * both (start of str / start of the line buffer, nuts333.c:1334, 2264). */
+void np_stage_feed(struct np_stage *st, const char *str, int colour, np_emit_fn emit, void *ctx)
 {
-    char buff[NP_OUT_BUFF + 8];
-    int pos = 0;
+    char *buff = st->buff;
+    int pos = st->pos;
     const char *const start = str;
 
     while (*str) {
@@ -160,7 +169,21 @@ void np_write_user_stream(const char *str, int colour, np_emit_fn emit, void *ct
         }
         if (pos == NP_OUT_BUFF) { emit(ctx, buff, NP_OUT_BUFF); pos = 0; }
     }
-    if (pos) emit(ctx, buff, (size_t)pos);
+    st->pos = pos;
+}
+
+void np_stage_flush(struct np_stage *st, np_emit_fn emit, void *ctx)
+{
+    if (st->pos) emit(ctx, st->buff, (size_t)st->pos);
+    st->pos = 0;
+}
+
+void np_write_user_stream(const char *str, int colour, np_emit_fn emit, void *ctx)
+{
+    struct np_stage st;
+    np_stage_init(&st);
+    np_stage_feed(&st, str, colour, emit, ctx);
+    np_stage_flush(&st, emit, ctx);
     if (colour) emit(ctx, "\033[0m", 4);
 }
 

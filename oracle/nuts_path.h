@@ -60,6 +60,11 @@ int np_command_lookup(const char *comword);
 
 /* ---- colour-markup transducer (nuts333.c:1315-1365, 2562-2610) ---- */
 typedef void (*np_emit_fn)(void *ctx, const char *buf, size_t len);
+/* The 1000-byte staging buffer of write_user / more() (nuts333.c:1296, 2211), kept across strings by more(). */
+struct np_stage { char buff[NP_OUT_BUFF + 8]; int pos; };
+void np_stage_init(struct np_stage *st);
+void np_stage_feed(struct np_stage *st, const char *str, int colour, np_emit_fn emit, void *ctx);
+void np_stage_flush(struct np_stage *st, np_emit_fn emit, void *ctx);
 /* Calls emit() once per write(2) the reference issues, with the same bytes. */
 void np_write_user_stream(const char *str, int colour, np_emit_fn emit, void *ctx);
 /* Concatenation of those chunks; returns the length needed (may exceed cap; no NUL). */

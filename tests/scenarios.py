@@ -24,6 +24,7 @@ What they pin, by reference function:
   login_paths   accept + 3-stage login incl. every error exit, new account, wizport,   c:263-311, 1451-1606, 1645-1673
                 ban list, hung-login takeover; the .D record written at logout
   capacity      max_users on the main port only                                        c:287-291
+  long_motd     more(): banners over 1 KB through the 1000-byte staging buffer            c:2205-2296
   netlink       two talkers: TRANS/GRANTED, ACT relay, MSG..EMSG frames, PRM,   c:2946-3073, 3077-3285, 1299-1306,
                 REMVD on the way home, offsite tell, home execution               3452-3479, 3787-3806, 4168-4172
   netlink_wire_* a scripted peer speaks the link protocol itself: every verb's    c:2892-2942, 2946-3073, 3077-3479,
@@ -670,6 +671,31 @@ def netlink_wire_dial():
             "wait_syslog": [(0, "Connected to peer2")], "script": script}
 
 
+#: banners over 1 KB whose newlines, colour commands and fill level land on the staging buffer's three flush rules
+#: (nuts333.c:2253-2255, 2272-2274, 2292-2294); shared with tests/test_harness.py, which compares write(2) counts
+LONG_MOTD1 = ("a" * 995 + "\n"                      # newline with 995 staged (> 994): flush first
+              + "b" * 993 + "~FRx\n"                 # '~' with 995 staged: flush first; colour off: the code vanishes
+              + "c" * 997 + "\n"                     # fills the buffer to exactly 1000: flush
+              + "/~FR escaped, ~ZZ unknown, the end of motd1\n\n")
+LONG_MOTD2 = ("a" * 990 + "~OLbbb\n"                 # colour on: 990 + ESC[1m + bbb = 997 staged at the newline
+              + "c" * 988 + "~FGd" + "e" * 30 + "~RS\n")   # 6 + 988 + ESC[32m = 999, 'd' makes 1000
+
+
+def long_motd():
+    """Pre- and post-login banners longer than the 1000-byte staging buffer of more() (nuts333.c:2205-2296), read
+    by a colour-on user: pins the bytes; the write(2) boundaries are compared in tests/test_harness.py."""
+    accounts = [_acc(A, colour=1), _acc(B)]
+
+    def script(s):
+        s.connect("a"); s.login("a", A, colour=True)
+        s.connect("b"); s.login("b", B)
+        s.line("a", "after the long banners")
+
+    return {"configs": lambda p: [pv.TalkerConfig(mainport=p[0][0], wizport=p[0][1], linkport=p[0][2], max_users=50)],
+            "accounts": [accounts], "boot_order": [0], "script": script,
+            "files": {"motd1": LONG_MOTD1, "motd2": LONG_MOTD2}}
+
+
 def netlink_wire_legacy():
     """Peers that announce an older protocol version get the older answers (nuts333.c:1299-1300, 3093-3097, 3129-3139,
     3141-3146): a banned or locked-out traveller is DENIED 6 instead of 9 / 8, a pre-3.3.1 TRANS carries no level word
@@ -764,4 +790,5 @@ SCENARIOS = {
     "netlink_wire_accept": netlink_wire_accept,
     "netlink_wire_dial": netlink_wire_dial,
     "netlink_wire_legacy": netlink_wire_legacy,
+    "long_motd": long_motd,
 }

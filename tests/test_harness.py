@@ -264,6 +264,63 @@ def test_small_workloads_against_the_reference(ref_binary):
     _check_link_frames(r5, lines=30, travellers=5)
 
 
+def _login_write_sizes(binary, tmp_path, tag, name, colour, shim):
+    """Sizes of the write(2) calls a talker issues on the client socket for: accept + motd1, then name / password +
+    motd2 + look, logged by the LD_PRELOAD shim tests/preload_writelog.c."""
+    import scenarios
+    import socket
+    import time
+    ports = free_ports(3)
+    root = pv.write_tree(tmp_path / tag, pv.TalkerConfig(mainport=ports[0], wizport=ports[1], linkport=ports[2]),
+                         [pv.Account(name, colour=colour)])
+    (root / "motd1").write_text(scenarios.LONG_MOTD1)
+    (root / "motd2").write_text(scenarios.LONG_MOTD2)
+    log = tmp_path / f"{tag}.writes"
+
+    def read_until(sock, needle):
+        buf = b""
+        while needle not in buf:
+            chunk = sock.recv(65536)
+            assert chunk, buf[-200:]
+            buf += chunk
+        return buf
+
+    os.environ.update(LD_PRELOAD=str(shim), WRITELOG=str(log))
+    try:
+        t = Talker(binary, root)
+        t.start()
+    finally:
+        os.environ.pop("LD_PRELOAD"); os.environ.pop("WRITELOG")
+    try:
+        s = socket.create_connection(("127.0.0.1", ports[0]), timeout=10)
+        got = read_until(s, b"Give me a name: ")
+        s.sendall(name.encode() + b"\n"); got += read_until(s, b"Give me a password: ")
+        s.sendall(b"test\n"); got += read_until(s, b"has been set yet.")
+        time.sleep(0.1)
+        s.close()
+    finally:
+        t.stop()
+    return [int(l.split()[1]) for l in log.read_text().splitlines()], got
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("colour", [0, 1])
+def test_more_flushes_where_the_reference_does_for_long_banners(tmp_path, ref_binary, port_binary, colour):
+    """more() stages a whole file through one 1000-byte buffer (nuts333.c:2205-2296); with banners over
+    1 KB the write(2) BOUNDARIES -- not just the bytes, and not just the count -- must match.  motd1 (pre-login, never
+    coloured) crosses all three flush rules: before a newline with > 994 staged, before a '~' with > 994 staged, and
+    at exactly 1000; motd2 is read with the account's colour flag."""
+    shim = tmp_path / "writelog.so"
+    subprocess.run(["gcc", "-O2", "-fPIC", "-shared", str(REPO / "tests" / "preload_writelog.c"), "-o", str(shim), "-ldl"], check=True)
+    ref, ref_bytes = _login_write_sizes(ref_binary, tmp_path, "ref", "Alice", colour, shim)
+    port, port_bytes = _login_write_sizes(port_binary, tmp_path, "port", "Alice", colour, shim)
+    assert ref_bytes == port_bytes
+    assert ref == port, (ref, port)
+    # motd1 as crafted in tests/scenarios.py: 995 | "\n\r" + 993 | "x\n\r" + 997 = 1000 | the rest
+    i = ref.index(995)
+    assert ref[i:i + 3] == [995, 995, 1000] and sum(ref) == len(ref_bytes)
+
+
 def test_loadgen_reports_a_rejected_login(tmp_path, port_binary):
     """Unprovisioned account -> the talker asks to confirm a new password -> hard failure, not a hang."""
     ports = free_ports(3)
