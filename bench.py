@@ -108,25 +108,28 @@ def config_entry(name: str, res: dict) -> dict:
 
 def all_configs(binary: Path, pin: bool, headline_name: str, headline: dict) -> list[dict]:
     """BASELINE.json's five configurations at their formal sizes (nuts333_amd/baseline.py).  The cheap ones (#1-#3,
-    about a second each) are repeated three times and the MEDIAN run is reported with all three rates beside it, as
-    the formal baseline does -- the first run on a shared host is often 5-10 % low.  The headline run is reused for
-    its own slot; #5 runs once: it takes ~15-30 s because neither talker sets TCP_NODELAY on the link (nuts333.c:1266)."""
+    and #4, one to three seconds each) are repeated three times and the MEDIAN run is reported with all three rates
+    beside it, as the formal baseline does: the GPU box's host is shared (load average 30-60 from other tenants), and a
+    neighbour landing on a sibling thread moves a single run by 5-30 %.  The headline run is the first of #4's three;
+    #5 runs once: it takes ~15-30 s because neither talker sets TCP_NODELAY on the link (nuts333.c:1266)."""
     plan = [("config1", 3, lambda: workloads.config1(lines=10_000, warmup=500, binary=binary, pin=pin)),
             ("config2", 3, lambda: workloads.config2(lines=20_000, warmup=1000, binary=binary, pin=pin)),
             ("config3", 3, lambda: workloads.config3(per_client=200, warmup=2, binary=binary, pin=pin)),
-            ("config4", 1, lambda: workloads.config4(lines=1000, warmup=20, binary=binary, pin=pin)),
+            ("config4", 3, lambda: workloads.config4(lines=1000, warmup=20, binary=binary, pin=pin)),
             ("config5", 1, lambda: workloads.config5(lines=1000, binary=binary, pin=pin))]
     out = []
     for name, reps, fn in plan:
         t = time.time()
-        runs = [headline] if name == headline_name else [fn() for _ in range(reps)]
+        # the headline's own slot: the contract's timed run plus fresh repetitions at the formal size, so that the
+        # line itself shows how far a single run on this (shared) host can sit from the median
+        runs = ([headline] + [fn() for _ in range(reps - 1)]) if name == headline_name else [fn() for _ in range(reps)]
         rate = (lambda r: r["delivered_lines_per_s"]) if runs[0]["expected_deliveries"] else (lambda r: r["input_lines_per_s"])
         med = sorted(runs, key=rate)[len(runs) // 2]
         e = config_entry(name, med)
         e["exact"] = bool(e["exact"] and all(r["exact"] for r in runs))
         e["reps"] = len(runs)
         e["rate_all_reps"] = [round(rate(r), 1) for r in runs]
-        e["is_headline_run"] = name == headline_name
+        e["includes_headline_run"] = name == headline_name
         out.append(e)
         print(f"[bench] {name}: {e['delivered_lines_per_s']:,.0f} delivered/s, {e['input_lines_per_s']:,.0f} input/s, "
               f"exact={e['exact']} ({time.time() - t:.1f}s)", file=sys.stderr, flush=True)
@@ -277,6 +280,10 @@ def main() -> int:
         if dist is not None:
             dist.barrier()
 
+    try:
+        loadavg0 = [float(x) for x in Path("/proc/loadavg").read_text().split()[:3]]
+    except (OSError, ValueError):
+        loadavg0 = None
     barrier()
     t_outer0 = time.perf_counter()
     res, failure = None, ""
@@ -346,6 +353,8 @@ def main() -> int:
                             "per_input_line": {"read": round(srv["read_syscalls_per_input_line"], 3),
                                                "write": round(srv["write_syscalls"] / max(1, res["input_lines"]), 3)}},
         "outer_wall_s": round(t_outer1 - t_outer0, 3), "login_s": res["login_s"],
+        "host": {"cpus_available": len(os.sched_getaffinity(0)), "loadavg_before_run": loadavg0,
+                 "note": "shared host: other tenants' load moves single runs; see configs[].rate_all_reps for the spread"},
     }
     baseline = {"value": round(res["delivered_lines_per_s"], 1), "unit": UNIT, "cores": 1, "kind": kind,
                 "sample": f"the timed run itself: {res['input_lines']} input lines, {res['deliveries']} deliveries, one replica"}
