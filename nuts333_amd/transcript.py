@@ -455,20 +455,15 @@ class Session:
         c = self.clients.pop(key)
         others = list(self.clients.values())
         c.sock.close()
-        # the talker notices on its next select(); sync the others until one sees SIGN OFF
-        deadline = time.monotonic() + 5.0
-        recv: dict[str, bytes] = {k.key: b"" for k in others}
-        while others and time.monotonic() < deadline:
-            got = self._collect(None)
-            for k, v in got.items():
-                recv[k] += v
-            if any(b"SIGN OFF:" in v for v in recv.values()):
-                # one more pass so every listener has it
-                got = self._collect(None)
-                for k, v in got.items():
-                    recv[k] += v
-                break
-            time.sleep(0.01)
+        # The talker notices on its next select() and writes the SIGN OFF broadcast to every listener in one pass
+        # (single-threaded).  Wait PASSIVELY for the first byte of it on any other client -- no round trips yet, so
+        # that the talker's own sequence of write(2) calls is a function of the script alone (the write-order parity
+        # test relies on that) -- then one round of syncs collects it everywhere.  Nobody listening (a half-open login
+        # closed, everyone ignoring): the wait times out and the round of syncs records the silence.
+        listeners = [o.sock for o in others if o.logged_in]     # a half-open login dropped by the talker reads EOF for ever
+        if listeners:
+            select.select(listeners, [], [], 0.5)
+        recv: dict[str, bytes] = self._collect(None) if others else {}
         self._record({"op": "close", "actor": key}, recv)
 
     def shutdown(self) -> None:

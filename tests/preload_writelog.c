@@ -6,7 +6,7 @@
  * strace is not available in this image and TCP coalesces segments, so the byte stream a client receives cannot
  * show where one write(2) ended and the next began; this can.  Used by tests/test_harness.py to check that the
  * restatement's more() / write_user() flush their 1000-byte staging buffer exactly where the reference does
- * (nuts333.c:1315-1365, 2250-2296).  One line per call: "<fd> <length>".
+ * (nuts333.c:1315-1365, 2250-2296).  One line per call: "<pid> <fd> <length>".
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -25,8 +25,8 @@ ssize_t write(int fd, const void *buf, size_t n)
     if (path && fstat(fd, &st) == 0 && S_ISSOCK(st.st_mode)) {
         int lf = open(path, O_WRONLY | O_APPEND | O_CREAT, 0644);
         if (lf >= 0) {
-            char line[48];
-            int l = snprintf(line, sizeof(line), "%d %zu\n", fd, n);
+            char line[64];
+            int l = snprintf(line, sizeof(line), "%d %d %zu\n", (int)getpid(), fd, n);
             if (real(lf, line, (size_t)l) < 0) {}
             close(lf);
         }

@@ -20,7 +20,16 @@ from nuts333_amd.transcript import Peer, Session
 import scenarios
 
 
-def run_scenario(name: str, binaries: Path | Sequence[Path]) -> dict:
+def build_writelog_shim(directory: Path) -> Path:
+    """Compile tests/preload_writelog.c (an LD_PRELOAD logger of write(2) sizes on sockets) into ``directory``."""
+    import subprocess
+    shim = Path(directory) / "writelog.so"
+    subprocess.run(["gcc", "-O2", "-fPIC", "-shared", str(Path(__file__).resolve().parent / "preload_writelog.c"),
+                    "-o", str(shim), "-ldl"], check=True)
+    return shim
+
+
+def run_scenario(name: str, binaries: Path | Sequence[Path], writelog_shim: Path | None = None) -> dict:
     spec = (scenarios.SCENARIOS.get(name) or scenarios.REFERENCE_ONLY[name])()
     if isinstance(spec, tuple):
         cfg_kw, accounts, script = spec
@@ -44,16 +53,33 @@ def run_scenario(name: str, binaries: Path | Sequence[Path]) -> dict:
             sess.peers[key] = Peer(key)
         cfgs = spec["configs"](ports, {k: p.port for k, p in sess.peers.items()}) if spec.get("peers") else spec["configs"](ports)
         try:
-            for i in spec["boot_order"]:
-                root = Path(tmp) / f"t{i}"
-                pv.write_tree(root, cfgs[i], spec["accounts"][i])
-                for rel, content in spec.get("files", {}).items():
-                    (root / rel).write_text(content)
-                talkers[i] = Talker(binaries[i], root)
-                talkers[i].start()
+            import os
+            wlog = Path(tmp) / "writes.log"
+            if writelog_shim is not None:
+                os.environ.update(LD_PRELOAD=str(writelog_shim), WRITELOG=str(wlog))
+            try:
+                for i in spec["boot_order"]:
+                    root = Path(tmp) / f"t{i}"
+                    pv.write_tree(root, cfgs[i], spec["accounts"][i])
+                    for rel, content in spec.get("files", {}).items():
+                        (root / rel).write_text(content)
+                    talkers[i] = Talker(binaries[i], root)
+                    talkers[i].start()
+            finally:
+                if writelog_shim is not None:
+                    os.environ.pop("LD_PRELOAD", None); os.environ.pop("WRITELOG", None)
             for i, needle in spec.get("wait_syslog", []):
                 talkers[i].wait_syslog(needle)
             spec["script"](sess)
+            # every client has just completed a .version round trip: all writes the script caused are done.  Read the
+            # log NOW -- what the talkers write while the clients are being closed below is a race with their SIGKILL.
+            write_sizes = None
+            if writelog_shim is not None:
+                by_pid: dict[int, list[int]] = {}
+                for ln in (wlog.read_text().splitlines() if wlog.exists() else []):
+                    pid, _fd, n = ln.split()
+                    by_pid.setdefault(int(pid), []).append(int(n))
+                write_sizes = [by_pid.get(t.pid, []) for t in talkers]
             alive = [t.alive() for t in talkers]
             sess.shutdown()
             # on-disk side effects the scenario wants pinned (user records written at logout)
@@ -78,4 +104,5 @@ def run_scenario(name: str, binaries: Path | Sequence[Path]) -> dict:
         "accounts": [[asdict(a) for a in accs] for accs in spec["accounts"]],
         "steps": sess.steps,
         **({"files": files} if spec.get("collect_files") else {}),
+        **({"write_sizes": write_sizes} if writelog_shim is not None else {}),
     }

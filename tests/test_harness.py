@@ -300,7 +300,7 @@ def _login_write_sizes(binary, tmp_path, tag, name, colour, shim):
         s.close()
     finally:
         t.stop()
-    return [int(l.split()[1]) for l in log.read_text().splitlines()], got
+    return [int(l.split()[2]) for l in log.read_text().splitlines()], got
 
 
 @pytest.mark.reference
@@ -310,8 +310,8 @@ def test_more_flushes_where_the_reference_does_for_long_banners(tmp_path, ref_bi
     1 KB the write(2) BOUNDARIES -- not just the bytes, and not just the count -- must match.  motd1 (pre-login, never
     coloured) crosses all three flush rules: before a newline with > 994 staged, before a '~' with > 994 staged, and
     at exactly 1000; motd2 is read with the account's colour flag."""
-    shim = tmp_path / "writelog.so"
-    subprocess.run(["gcc", "-O2", "-fPIC", "-shared", str(REPO / "tests" / "preload_writelog.c"), "-o", str(shim), "-ldl"], check=True)
+    from scenario_runner import build_writelog_shim
+    shim = build_writelog_shim(tmp_path)
     ref, ref_bytes = _login_write_sizes(ref_binary, tmp_path, "ref", "Alice", colour, shim)
     port, port_bytes = _login_write_sizes(port_binary, tmp_path, "port", "Alice", colour, shim)
     assert ref_bytes == port_bytes

@@ -92,6 +92,32 @@ def test_write_boundaries(lib):
     assert lib.np_write_count(b"", 0) == 0 and lib.np_write_count(b"", 1) == 1
 
 
+def test_stage_keeps_its_fill_level_across_strings(lib):
+    """np_stage_*: the staging buffer as more() uses it (nuts333.c:2250-2296) -- fed line by line, flushed once at the end.
+    The chunk sizes are the reference's own write(2) sizes for this file, logged from the real talker by
+    tests/test_harness.py::test_more_flushes_where_the_reference_does_for_long_banners: 995 | 995 | 1000 | rest."""
+    import scenarios
+
+    class Stage(ctypes.Structure):
+        _fields_ = [("buff", ctypes.c_char * 1008), ("pos", ctypes.c_int)]
+
+    EMIT = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_char), ctypes.c_size_t)
+    chunks = []
+    emit = EMIT(lambda ctx, buf, n: chunks.append(ctypes.string_at(buf, n)))
+    lib.np_stage_init.argtypes = [ctypes.POINTER(Stage)]
+    lib.np_stage_feed.argtypes = [ctypes.POINTER(Stage), ctypes.c_char_p, ctypes.c_int, EMIT, ctypes.c_void_p]
+    lib.np_stage_flush.argtypes = [ctypes.POINTER(Stage), EMIT, ctypes.c_void_p]
+    st_ = Stage()
+    lib.np_stage_init(ctypes.byref(st_))
+    for line in scenarios.LONG_MOTD1.splitlines(keepends=True):
+        lib.np_stage_feed(ctypes.byref(st_), line.encode(), 0, emit, None)
+    lib.np_stage_flush(ctypes.byref(st_), emit, None)
+    assert [len(c) for c in chunks][:3] == [995, 995, 1000]
+    whole = b"".join(chunks)
+    assert whole == b"".join(transduce(lib, l.encode(), 0) for l in scenarios.LONG_MOTD1.splitlines(keepends=True))
+    assert whole.endswith(b"~FR escaped, ~ZZ unknown, the end of motd1\n\r\n\r")
+
+
 PRINTABLE = st.text(alphabet=st.sampled_from(list("abcXYZ ~/FRSOLBG0123\n")), max_size=300)
 
 

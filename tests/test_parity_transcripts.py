@@ -71,6 +71,35 @@ def test_reference_still_matches_golden(name, ref_binary):
     assert got.get("files") == gold.get("files")
 
 
+@pytest.fixture(scope="module")
+def writelog_shim(tmp_path_factory):
+    from scenario_runner import build_writelog_shim
+    return build_writelog_shim(tmp_path_factory.mktemp("shim"))
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("name", NAMES)
+def test_same_write_calls_in_the_same_order_as_the_reference(name, ref_binary, port_binary, writelog_shim):
+    """Stronger than equal bytes: the restatement issues the same write(2) calls -- same sizes, same order, on client
+    sockets and netlinks -- as the reference over the whole session (login, look, every command, every relay).  TCP
+    hides write boundaries from a client; an LD_PRELOAD shim (tests/preload_writelog.c) logs them inside each talker.
+    This is what makes the restatement's system-call cost representative when it stands in as cpu_baseline "port"."""
+    ref = run_scenario(name, ref_binary, writelog_shim)["write_sizes"]
+    port = run_scenario(name, port_binary, writelog_shim)["write_sizes"]
+    assert [len(x) for x in ref] == [len(x) for x in port], "different number of write(2) calls"
+    if len(ref) > 1:
+        # two live talkers: whether a frame from the other talker or a local client's line is served first within one
+        # select() wake-up depends on arrival time, so the ORDER of a talker's writes is not a function of the script
+        # (seen: two adjacent writes swapped in 1 run of 3, in the reference as much as in the restatement).  Same calls,
+        # same sizes, any order.
+        ref, port = [sorted(x) for x in ref], [sorted(x) for x in port]
+    for t, (a, b) in enumerate(zip(ref, port)):
+        if a != b:
+            i = next(i for i, (x, y) in enumerate(zip(a, b)) if x != y)
+            raise AssertionError(f"talker {t}: write #{i} of {len(a)}: reference {a[max(0, i - 3):i + 4]} restatement {b[max(0, i - 3):i + 4]}")
+    assert all(len(x) > 20 for x in ref)
+
+
 @pytest.mark.reference
 @pytest.mark.parametrize("order", ["port_dials_reference", "reference_dials_port"])
 def test_netlink_interop_with_reference(order, port_binary, ref_binary):
