@@ -106,7 +106,7 @@ def config_entry(name: str, res: dict) -> dict:
     return out
 
 
-def all_configs(binary: Path, pin: bool, headline_name: str, headline: dict) -> list[dict]:
+def all_configs(binary: Path, pin: bool, headline_name: str, headline: dict, attempt) -> list[dict]:
     """BASELINE.json's five configurations at their formal sizes (nuts333_amd/baseline.py).  The cheap ones (#1-#3,
     and #4, one to three seconds each) are repeated three times and the MEDIAN run is reported with all three rates
     beside it, as the formal baseline does: the GPU box's host is shared (load average 30-60 from other tenants), and a
@@ -122,11 +122,15 @@ def all_configs(binary: Path, pin: bool, headline_name: str, headline: dict) -> 
         t = time.time()
         # the headline's own slot: the contract's timed run plus fresh repetitions at the formal size, so that the
         # line itself shows how far a single run on this (shared) host can sit from the median
-        runs = ([headline] + [fn() for _ in range(reps - 1)]) if name == headline_name else [fn() for _ in range(reps)]
+        runs = [headline] if name == headline_name else []
+        runs += [r for r in (attempt(f"{name} repetition {k + 1}", fn) for k in range(reps - len(runs))) if r is not None]
+        if not runs:
+            out.append({"name": name, "exact": False, "error": "no repetition completed (see extras_errors)"})
+            continue
         rate = (lambda r: r["delivered_lines_per_s"]) if runs[0]["expected_deliveries"] else (lambda r: r["input_lines_per_s"])
         med = sorted(runs, key=rate)[len(runs) // 2]
         e = config_entry(name, med)
-        e["exact"] = bool(e["exact"] and all(r["exact"] for r in runs))
+        e["exact"] = bool(e["exact"] and all(r["exact"] for r in runs) and len(runs) == reps)
         e["reps"] = len(runs)
         e["rate_all_reps"] = [round(rate(r), 1) for r in runs]
         e["includes_headline_run"] = name == headline_name
@@ -360,22 +364,40 @@ def main() -> int:
                 "sample": f"the timed run itself: {res['input_lines']} input lines, {res['deliveries']} deliveries, one replica"}
     roofline = None
     if not args.no_extras and world == 1:
-        roofline = syscall_roofline(res, written_all / wall_max)
+        # Everything below is context for the headline number, not part of it: a failure here (a probe that cannot
+        # open 2000 descriptors, a talker that will not boot on a busy host) must not cost the driver its result
+        # line.  It is reported in the line (`extras_errors`) and on stderr instead.
+        errors: list[str] = []
+
+        def attempt(what: str, fn):
+            try:
+                return fn()
+            except Exception:
+                errors.append(f"{what}: {traceback.format_exc(limit=3)}")
+                print(f"[bench] {what} failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+                return None
+
+        roofline = attempt("syscall roofline probe", lambda: syscall_roofline(res, written_all / wall_max))
         if kind == "reference" and PORT_BINARY.exists():
-            p = run_workload(args.workload, total, warm, PORT_BINARY, pin)
-            out["cpu_baseline_port"] = {"value": round(p["delivered_lines_per_s"], 1), "unit": UNIT, "cores": 1, "kind": "port",
-                                        "sample": f"same workload and size as the timed run: {p['input_lines']} input lines, "
-                                                  f"{p['deliveries']} deliveries", "exact": p["exact"],
-                                        "server_cpu_us_per_written_line": round(p["servers"][0]["cpu_us_per_written_line"], 3)}
-        out["configs"] = all_configs(binary, pin, args.workload, res)
-        out["configs_all_exact"] = all(e["exact"] for e in out["configs"])
-        out["device_floor"] = device_floor()
+            p = attempt("restatement on the headline workload", lambda: run_workload(args.workload, total, warm, PORT_BINARY, pin))
+            if p is not None:
+                out["cpu_baseline_port"] = {"value": round(p["delivered_lines_per_s"], 1), "unit": UNIT, "cores": 1, "kind": "port",
+                                            "sample": f"same workload and size as the timed run: {p['input_lines']} input lines, "
+                                                      f"{p['deliveries']} deliveries", "exact": p["exact"],
+                                            "server_cpu_us_per_written_line": round(p["servers"][0]["cpu_us_per_written_line"], 3)}
+        out["configs"] = all_configs(binary, pin, args.workload, res, attempt)
+        out["configs_all_exact"] = all(e.get("exact", False) for e in out["configs"])
+        out["device_floor"] = attempt("device floor", device_floor)
+        out["extras_errors"] = errors
     out["roofline"] = roofline
     out["cpu_baseline"] = baseline
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
-    return 0 if out.get("configs_all_exact", True) else 1
+    # the exit code speaks for the contract's timed run only; the extras speak for themselves in the line
+    if not out.get("configs_all_exact", True):
+        print("[bench] WARNING: not every configuration in `configs` completed exactly -- see the line", file=sys.stderr, flush=True)
+    return 0
 
 
 if __name__ == "__main__":

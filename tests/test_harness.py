@@ -390,6 +390,40 @@ def test_bench_single_replica_contract():
     assert j["configs"][4]["netlink"]["writes_t2_to_t1"] == 11000 and j["configs"][4]["netlink"]["writes_t1_to_t2"] == 1000
 
 
+def test_bench_extras_cannot_cost_the_result_line(monkeypatch):
+    """A configuration that fails inside `configs` is reported in the line, the others still run (aggregation logic
+    only: the workloads are stubbed)."""
+    sys.path.insert(0, str(REPO))
+    import bench
+
+    def fake(rate, n, deliveries=10):
+        return {"clients": n, "workload": "stub", "delivered_lines_per_s": rate, "input_lines_per_s": rate / 10, "input_lines": 1,
+                "deliveries": deliveries, "expected_deliveries": deliveries, "wall_s": 1.0, "exact": True,
+                "ack_latency_us": {"p50": 1.0}, "servers": [{"cpu_us_per_written_line": 1.0, "busy_frac": 1.0}]}
+
+    rates = iter([300.0, 100.0, 200.0])
+    monkeypatch.setattr(bench.workloads, "config1", lambda **kw: fake(next(rates), 1))
+    monkeypatch.setattr(bench.workloads, "config2", lambda **kw: (_ for _ in ()).throw(RuntimeError("talker did not boot")))
+    monkeypatch.setattr(bench.workloads, "config3", lambda **kw: fake(5.0, 100))
+    monkeypatch.setattr(bench.workloads, "config4", lambda **kw: fake(7.0, 1000))
+    monkeypatch.setattr(bench.workloads, "config5", lambda **kw: {**fake(9.0, 20), "netlink": {"exact": True}})
+    errors = []
+
+    def attempt(what, fn):
+        try:
+            return fn()
+        except Exception as e:
+            errors.append(f"{what}: {e}")
+            return None
+
+    out = bench.all_configs(Path("x"), True, "config4", fake(8.0, 1000), attempt)
+    assert [e["name"] for e in out] == ["config1", "config2", "config3", "config4", "config5"]
+    assert out[0]["delivered_lines_per_s"] == 200.0 and out[0]["rate_all_reps"] == [300.0, 100.0, 200.0]     # the median run
+    assert out[1]["exact"] is False and "error" in out[1] and len(errors) == 3
+    assert out[3]["includes_headline_run"] and out[3]["reps"] == 3 and out[3]["rate_all_reps"] == [8.0, 7.0, 7.0]
+    assert out[4]["exact"] and out[4]["netlink"] == {"exact": True}
+
+
 def test_bench_default_headline_is_the_largest_configuration():
     """Driver default: BASELINE configs[3] -- 1000 clients, .shout.  Headline leg only here."""
     j = _bench("--steps", "2", "--warmup", "1", "--binary", "port", "--no-extras")
