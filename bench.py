@@ -276,6 +276,11 @@ def main() -> int:
         ensure_built()
     pin = len(os.sched_getaffinity(0)) >= 2
     binary, kind = workloads.pick_binary(args.binary)
+    # several replicas under one cgroup CPU quota: keep (1 talker + receivers) x replicas inside it, or the kernel
+    # throttles the whole container and the "scaling" measured is the quota's
+    quota = workloads.cgroup_cpu_quota()
+    if quota is not None:
+        workloads.MAX_CLIENT_THREADS = max(1, min(4, int(quota / world - 1.5)))
 
     total = args.steps * lines_per_step
     warm = args.warmup * lines_per_step
@@ -288,6 +293,7 @@ def main() -> int:
         loadavg0 = [float(x) for x in Path("/proc/loadavg").read_text().split()[:3]]
     except (OSError, ValueError):
         loadavg0 = None
+    throttled0 = workloads.cgroup_throttled()
     barrier()
     t_outer0 = time.perf_counter()
     res, failure = None, ""
@@ -300,6 +306,7 @@ def main() -> int:
     except Exception:                           # a dead replica must not leave the others waiting in a collective
         failure = traceback.format_exc()
     t_outer1 = time.perf_counter()
+    throttled1 = workloads.cgroup_throttled()
     ok = 0.0 if failure else 1.0
     if dist is not None:
         flag = torch.tensor([ok], dtype=torch.float64)
@@ -358,6 +365,8 @@ def main() -> int:
                                                "write": round(srv["write_syscalls"] / max(1, res["input_lines"]), 3)}},
         "outer_wall_s": round(t_outer1 - t_outer0, 3), "login_s": res["login_s"],
         "host": {"cpus_available": len(os.sched_getaffinity(0)), "loadavg_before_run": loadavg0,
+                 "cgroup_cpu_quota_cores": quota, "receiver_threads_per_replica": res["threads"],
+                 "cgroup_throttled_periods_during_run": (throttled1[0] - throttled0[0]) if throttled0 and throttled1 else None,
                  "note": "shared host: other tenants' load moves single runs; see configs[].rate_all_reps for the spread"},
     }
     baseline = {"value": round(res["delivered_lines_per_s"], 1), "unit": UNIT, "cores": 1, "kind": kind,

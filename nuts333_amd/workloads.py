@@ -59,6 +59,32 @@ def host_cpus() -> list[int]:
     return sorted(os.sched_getaffinity(0))
 
 
+#: upper bound on busy-polling receiver threads per load-generator process; bench.py lowers it when several replicas
+#: share one cgroup CPU quota (see cgroup_cpu_quota)
+MAX_CLIENT_THREADS = 4
+
+
+def cgroup_cpu_quota() -> float | None:
+    """CPU-time quota of this container in cores (cgroup v2 ``cpu.max``), or None when unlimited / unknown.  The
+    one-GPU MI355X box allows 16 cores' worth of CPU time although all 256 CPUs are schedulable: a talker plus four
+    spinning receivers per replica fits twice, not four times -- the fourth replica gets throttled, which would be
+    a property of the quota, not of the talker."""
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        return None if quota == "max" else int(quota) / int(period)
+    except (OSError, ValueError):
+        return None
+
+
+def cgroup_throttled() -> tuple[int, int] | None:
+    """(nr_throttled, throttled_usec) of this container so far, or None."""
+    try:
+        d = dict(l.split() for l in Path("/sys/fs/cgroup/cpu.stat").read_text().splitlines())
+        return int(d["nr_throttled"]), int(d["throttled_usec"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def pick_binary(kind: str = "auto") -> tuple[Path, str]:
     """('reference' | 'port' | 'auto') -> (binary path, kind actually used)."""
     if kind == "port_fast":
@@ -144,7 +170,7 @@ def run_spec(spec: Spec, talkers: Sequence[Talker], *, timeout_s: float = 600.0,
         # (or a second CCD) inflates the *server's* CPU per line by ~45 % (1.38 -> 2.0+ us on an EPYC
         # 9575F, profiles/sweep_loadgen_threads_r01_mi355xhost.log).  2-7 threads measure the same; 1 is
         # client-bound.  4 is the portable choice.
-        threads = max(1, min(len(client_cpus) or len(cpus) - 1 or 1, 4, len(spec.clients)))
+        threads = max(1, min(len(client_cpus) or len(cpus) - 1 or 1, MAX_CLIENT_THREADS, len(spec.clients)))
     # the talker listens with backlog 10 (nuts333.c:1189): keep concurrent logins below it
     login_window = max(1, 8 // threads)
     # talker<->talker traffic sits behind Nagle + delayed ACK (neither side sets TCP_NODELAY): wait longer
