@@ -174,7 +174,10 @@ def test_bench_line_covers_all_five_configs_headline_config4():
     assert j["config"]["baseline_config"] == "config4" and j["config"]["clients"] == 1000 and j["gpu_used"] is False
     assert j["delivered"] == j["expected_delivered"] == 5 * 100 * 999
     assert [c["name"] for c in j["configs"]] == ["config1", "config2", "config3", "config4", "config5"]
-    assert all(c["exact"] for c in j["configs"]) and j["configs_all_exact"]
+    assert all(c["exact"] for c in j["configs"]) and j["configs_all_exact"] and j["extras_errors"] == []
+    assert [c["reps"] for c in j["configs"]] == [3, 3, 3, 3, 1]
+    assert j["configs"][4]["netlink"]["exact"] and j["configs"][4]["netlink"]["writes_t2_to_t1"] == 11000
+    assert j["host"]["cgroup_throttled_periods_during_run"] in (0, None)
     r = j["roofline"]
     assert r["per_input_line"]["write"] == 1000 and r["per_input_line"]["select"] == 1 and r["per_input_line"]["read"] == 1
     assert r["peak"] == min(r["peak_closed_loop_cpu_time"], r["peak_open_loop_wall_demonstrated"]) and 0.3 < r["frac"] < 1.2

@@ -385,7 +385,7 @@ def test_bench_single_replica_contract():
     assert "model" not in j["config"] and "workload" in j["config"]
     # every BASELINE configuration is in the same line, exact, with measured link frames for #5
     names = [c["name"] for c in j["configs"]]
-    assert names == ["config1", "config2", "config3", "config4", "config5"] and j["configs_all_exact"]
+    assert names == ["config1", "config2", "config3", "config4", "config5"] and j["configs_all_exact"] and j["extras_errors"] == []
     assert [c["n"] for c in j["configs"]] == [1, 10, 100, 1000, 20] and [c["reps"] for c in j["configs"]] == [3, 3, 3, 3, 1]
     assert j["configs"][4]["netlink"]["writes_t2_to_t1"] == 11000 and j["configs"][4]["netlink"]["writes_t1_to_t2"] == 1000
 
