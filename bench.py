@@ -47,7 +47,7 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 from nuts333_amd import workloads  # noqa: E402
-from nuts333_amd.talker import PORT_BINARY, REF_BINARY  # noqa: E402
+from nuts333_amd.talker import PORT_BINARY  # noqa: E402
 
 METRIC = "delivered_broadcast_lines_per_s"
 UNIT = "lines/s"

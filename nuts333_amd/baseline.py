@@ -21,7 +21,7 @@ import time
 from pathlib import Path
 
 from . import workloads
-from .talker import PORT_BINARY, REF_BINARY, REF_BINARY_O0
+from .talker import REF_BINARY_O0
 
 
 def host_info() -> dict:

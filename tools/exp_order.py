@@ -1,4 +1,6 @@
-import json, subprocess, sys, time, os
+"""Ad-hoc: does run order / TIME_WAIT / idle time / core group move the numbers on this host? (run on the MI355X box;
+output kept in profiles/hostnoise_r02_mi355xhost.log)"""
+import os, subprocess, sys, time
 sys.path.insert(0, os.getcwd())
 from nuts333_amd import workloads
 from nuts333_amd.talker import REF_BINARY
