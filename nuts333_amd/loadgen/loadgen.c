@@ -576,14 +576,14 @@ static int probe_write(int bytes, long count) {
 #include <sys/select.h>
 
 #define PROBE_MAX_READERS 16
-struct lp_reader { int epfd, cpu, sender_cfd, line, open_loop; atomic_int *stop; atomic_ullong rx; pthread_t tid; };
+struct lp_reader { int epfd, cpu, sender_cfd, line, ack_bytes; atomic_int *stop; atomic_ullong rx; pthread_t tid; };
 
 static void *lp_reader_main(void *arg) {
     struct lp_reader *rd = arg; char *buf = malloc(RBUF); struct epoll_event evs[256];
     char line[1024]; memset(line, 'i', sizeof(line));
     if (rd->cpu >= 0) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(rd->cpu, &set); pthread_setaffinity_np(pthread_self(), sizeof(set), &set); }
     line[rd->line - 1] = '\n';
-    unsigned long long sender_rx = 0, sender_lines = 0; int ackbytes = rd->open_loop; /* reused: bytes per ack */
+    unsigned long long sender_rx = 0, sender_lines = 0; int ackbytes = rd->ack_bytes;   /* every ack is one BYTES-long line */
     while (!atomic_load(rd->stop)) {
         int n = epoll_wait(rd->epfd, evs, 256, 0);
         for (int i = 0; i < n; i++) {
@@ -622,7 +622,7 @@ static int probe_line(int bytes, int k, long rounds, int selread, int open_loop,
     struct lp_reader rd[PROBE_MAX_READERS];
     for (int r = 0; r < nreaders; r++) {
         rd[r].epfd = epoll_create1(0); rd[r].cpu = nrcpus ? rcpus[r % nrcpus] : -1; rd[r].sender_cfd = -1;
-        rd[r].line = LINE; rd[r].open_loop = bytes; rd[r].stop = &stop; atomic_init(&rd[r].rx, 0);
+        rd[r].line = LINE; rd[r].ack_bytes = bytes; rd[r].stop = &stop; atomic_init(&rd[r].rx, 0);
     }
     int sender_cfd = -1;
     for (int i = 0; i < nsock; i++) {
