@@ -4,8 +4,9 @@ The hand-written scenarios in tests/scenarios.py pin what we thought of; this pi
 not.  For each seed a random but reproducible script is generated from the commands on (and next
 to) the hot path -- speech in all its forms with markup-dense text, toggles, movement, review
 buffers, clones, level-scoped shouts -- and executed, one step at a time, against both talkers.
-Every byte every client receives at every step must agree.  Needs the reference build, so it
-runs in the build container only.
+Every byte every client receives at every step must agree -- and so must the sequence of write(2)
+calls each talker issued to produce them (sizes and order, logged by an LD_PRELOAD shim).  Needs the
+reference build; runs wherever oracle/_ref/ is present.
 """
 from __future__ import annotations
 
@@ -109,16 +110,29 @@ def make_script(seed: int):
     return cfg, accounts, script
 
 
+@pytest.fixture(scope="module")
+def writelog_shim(tmp_path_factory):
+    from scenario_runner import build_writelog_shim
+    return build_writelog_shim(tmp_path_factory.mktemp("shim"))
+
+
 @pytest.mark.reference
 @pytest.mark.parametrize("seed", [333, 1996, 7, 20261004, 42, 31337] + list(range(100, 118)))
-def test_random_sessions_agree(seed, ref_binary, port_binary, monkeypatch):
+def test_random_sessions_agree(seed, ref_binary, port_binary, monkeypatch, writelog_shim):
     name = f"__fuzz_{seed}"
     monkeypatch.setitem(scenarios.SCENARIOS, name, lambda: make_script(seed))
-    ref = run_scenario(name, ref_binary)["steps"]
-    port = run_scenario(name, port_binary)["steps"]
+    ref_run = run_scenario(name, ref_binary, writelog_shim)
+    port_run = run_scenario(name, port_binary, writelog_shim)
+    ref, port = ref_run["steps"], port_run["steps"]
     assert len(ref) == len(port)
     for i, (a, b) in enumerate(zip(ref, port)):
         assert a == b, f"seed {seed}, step {i}: {a.get('actor')} sent {a.get('send')!r}\n reference: {a['recv']}\n port     : {b['recv']}"
+    # ... and the same write(2) calls behind those bytes: sizes and order (tests/preload_writelog.c); the random text
+    # includes lines long enough to cross write_user's 1000-byte staging buffer (nuts333.c:1359-1363)
+    a, b = ref_run["write_sizes"][0], port_run["write_sizes"][0]
+    if a != b:
+        i = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
+        raise AssertionError(f"seed {seed}: write #{i} of {len(a)}/{len(b)}: reference {a[max(0, i - 3):i + 4]} restatement {b[max(0, i - 3):i + 4]}")
     monkeypatch.setenv("NUTS_PORT_FAST", "1")
     fast = run_scenario(name, port_binary)["steps"]
     assert fast == ref, f"seed {seed}: fast mode diverges"
