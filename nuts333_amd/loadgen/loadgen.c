@@ -77,6 +77,9 @@ struct worker {
     int next_login, inflight, ready;
     uint64_t *lat; size_t nlat, caplat;
     int cpu;
+    /* this thread over the timed window: CPU time it got and time it sat runnable on a run queue.  The workers
+       busy-poll, so cpu/wall < 1 means the thread was descheduled (a neighbour on its core, or a cgroup throttle) */
+    uint64_t cpu0_ns, cpu1_ns, rq0_ns, rq1_ns;
 };
 
 static struct client *g_clients; static int g_nclients, g_capclients;
@@ -109,6 +112,20 @@ static uint64_t now_ns(void) {
 }
 
 static void die(const char *msg) { perror(msg); exit(2); }
+
+static uint64_t thread_cpu_ns(void) {
+    struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+/* second field of a schedstat file: ns spent runnable but waiting for a CPU (0 when the kernel keeps no schedstats) */
+static uint64_t schedstat_run_delay(const char *path) {
+    unsigned long long run = 0, delay = 0; FILE *fp = fopen(path, "r");
+    if (!fp) return 0;
+    if (fscanf(fp, "%llu %llu", &run, &delay) != 2) delay = 0;
+    fclose(fp);
+    return delay;
+}
 
 static void failf(struct client *c, const char *what) {
     fprintf(stderr, "loadgen: client %d (%s): %s (state %d, acc=%.*s)\n", c ? c->idx : -1,
@@ -450,6 +467,7 @@ static void *worker_main(void *arg) {
             pthread_barrier_wait(&g_run_barrier);   /* main records t0 then joins */
             pthread_barrier_wait(&g_run_barrier);
             started_run = 1;
+            w->cpu0_ns = thread_cpu_ns(); w->rq0_ns = schedstat_run_delay("/proc/thread-self/schedstat");
             for (int i = 0; i < w->ncl; i++) send_next(w->cl[i]);
             continue;
         }
@@ -470,6 +488,9 @@ static void *worker_main(void *arg) {
                 if (phase == 2 && tot >= g_expect_lines && !atomic_exchange(&g_done, 1))
                     atomic_store(&g_t_end, now_ns());
             }
+            if (!w->cpu1_ns && atomic_load(&g_done)) {
+                w->cpu1_ns = thread_cpu_ns(); w->rq1_ns = schedstat_run_delay("/proc/thread-self/schedstat");
+            }
         }
     }
     free(rbuf);
@@ -477,7 +498,7 @@ static void *worker_main(void *arg) {
 }
 
 /* ------------------------------------------------------------------ /proc sampling */
-struct cpu_sample { double utime_s, stime_s; uint64_t sched_ns, syscr, syscw, wchar; };
+struct cpu_sample { double utime_s, stime_s; uint64_t sched_ns, rq_ns, vcsw, ivcsw, syscr, syscw, wchar; };
 
 static void sample_pid(int pid, struct cpu_sample *s) {
     char path[64], buf[1024]; memset(s, 0, sizeof(*s));
@@ -496,7 +517,25 @@ static void sample_pid(int pid, struct cpu_sample *s) {
     }
     snprintf(path, sizeof(path), "/proc/%d/schedstat", pid);
     fp = fopen(path, "r");
-    if (fp) { unsigned long long ns = 0; if (fscanf(fp, "%llu", &ns) == 1) s->sched_ns = ns; fclose(fp); }
+    if (fp) {
+        unsigned long long ns = 0, rq = 0;
+        int got = fscanf(fp, "%llu %llu", &ns, &rq);
+        if (got >= 1) s->sched_ns = ns;
+        if (got >= 2) s->rq_ns = rq;       /* runnable, waiting for the CPU: contention on the talker's core or a throttle */
+        fclose(fp);
+    }
+    /* voluntary switches = the talker went to sleep (select with nothing to read, or write(2) into a full socket);
+       involuntary = something else took its core */
+    snprintf(path, sizeof(path), "/proc/%d/status", pid);
+    fp = fopen(path, "r");
+    if (fp) {
+        while (fgets(buf, sizeof(buf), fp)) {
+            unsigned long long v;
+            if (sscanf(buf, "voluntary_ctxt_switches: %llu", &v) == 1) s->vcsw = v;
+            else if (sscanf(buf, "nonvoluntary_ctxt_switches: %llu", &v) == 1) s->ivcsw = v;
+        }
+        fclose(fp);
+    }
     /* exact read/write system-call counts of the talker: /proc/<pid>/io (same uid) */
     snprintf(path, sizeof(path), "/proc/%d/io", pid);
     fp = fopen(path, "r");
@@ -576,7 +615,7 @@ static int probe_write(int bytes, long count) {
 #include <sys/select.h>
 
 #define PROBE_MAX_READERS 16
-struct lp_reader { int epfd, cpu, sender_cfd, line, ack_bytes; atomic_int *stop; atomic_ullong rx; pthread_t tid; };
+struct lp_reader { int epfd, cpu, sender_cfd, line, ack_bytes, feed; atomic_int *stop; atomic_ullong rx; pthread_t tid; };
 
 static void *lp_reader_main(void *arg) {
     struct lp_reader *rd = arg; char *buf = malloc(RBUF); struct epoll_event evs[256];
@@ -591,14 +630,16 @@ static void *lp_reader_main(void *arg) {
             while ((r = recv(fd, buf, RBUF, MSG_DONTWAIT)) > 0) got += (unsigned long long)r;
             int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_QUICKACK, &one, sizeof(one));
             atomic_fetch_add(&rd->rx, got);
-            if (fd == rd->sender_cfd) {
-                /* one new input line per ack received, each its own segment (TCP_NODELAY on the client side) */
-                sender_rx += got;
-                while (sender_lines < sender_rx / (unsigned long long)ackbytes) {
-                    if (send(fd, line, (size_t)rd->line, MSG_NOSIGNAL) < 0 && errno != EAGAIN) break;
-                    sender_lines++;
-                }
-            }
+            if (fd == rd->sender_cfd) sender_rx += got;
+        }
+        /* One new input line per ack received, each its own segment (TCP_NODELAY on the client side) -- but only
+           when the talker thread reads them (feed = the select+read legs).  In the write-only leg nobody reads the
+           sender's socket: lines sent there would pile up until the buffers fill and this thread blocks in send(),
+           stops draining, and the talker thread waits for bytes that never arrive (hung for
+           rounds x 60 B above the socket buffers).  Never block here: EAGAIN = try again on the next turn. */
+        while (rd->feed && rd->sender_cfd >= 0 && sender_lines < sender_rx / (unsigned long long)ackbytes) {
+            if (send(rd->sender_cfd, line, (size_t)rd->line, MSG_NOSIGNAL | MSG_DONTWAIT) < 0) break;
+            sender_lines++;
         }
     }
     free(buf); return NULL;
@@ -622,7 +663,7 @@ static int probe_line(int bytes, int k, long rounds, int selread, int open_loop,
     struct lp_reader rd[PROBE_MAX_READERS];
     for (int r = 0; r < nreaders; r++) {
         rd[r].epfd = epoll_create1(0); rd[r].cpu = nrcpus ? rcpus[r % nrcpus] : -1; rd[r].sender_cfd = -1;
-        rd[r].line = LINE; rd[r].ack_bytes = bytes; rd[r].stop = &stop; atomic_init(&rd[r].rx, 0);
+        rd[r].line = LINE; rd[r].ack_bytes = bytes; rd[r].feed = selread; rd[r].stop = &stop; atomic_init(&rd[r].rx, 0);
     }
     int sender_cfd = -1;
     for (int i = 0; i < nsock; i++) {
@@ -745,6 +786,8 @@ int main(int argc, char **argv) {
     uint64_t t_login1 = now_ns();
     struct cpu_sample s0[MAX_SERVERS], s1[MAX_SERVERS], s2[MAX_SERVERS];
     uint64_t t0 = 0, t1 = 0; int timed_out = 0;
+    const uint64_t GAP_NS = 5000000ull;      /* 5 ms without a single line anywhere */
+    uint64_t gap_seen = 0, gap_seen_at = 0, gap_idle_poll = 0, gap_max = 0, gap_total = 0; unsigned gap_n = 0;
     double warm_s = 0.0;
     if (!atomic_load(&g_fail) && g_expect_warm) {
         uint64_t w0 = now_ns();
@@ -772,15 +815,26 @@ int main(int argc, char **argv) {
         atomic_store(&g_phase, 2);
         pthread_barrier_wait(&g_run_barrier);
         uint64_t last_prog = t0, last_lines = 0;
+        gap_seen_at = t0;
         while (!atomic_load(&g_done) && !atomic_load(&g_fail)) {
             usleep(500);
             uint64_t n = now_ns();
             if (n > deadline) { timed_out = 1; break; }
             {
-                static uint64_t seen, seen_at;
+                /* progress gaps: intervals in which NO line reached ANY client.  A gap is counted from the moment
+                   progress was last seen to the last poll that still saw none, so a late wake-up of this thread
+                   cannot invent one.  In a saturating single-talker run lines arrive every 1-2 us: a gap of
+                   milliseconds means the talker (or the one sender that feeds it) was not running. */
                 uint64_t l = atomic_load(&g_lines);
-                if (!seen_at || l != seen) { seen = l; seen_at = n; }
-                if ((double)(n - seen_at) > g_stall_s * 1e9) {
+                if (l != gap_seen) {
+                    if (gap_idle_poll > gap_seen_at) {
+                        uint64_t gap = gap_idle_poll - gap_seen_at;
+                        if (gap > gap_max) gap_max = gap;
+                        if (gap >= GAP_NS) { gap_n++; gap_total += gap; }
+                    }
+                    gap_seen = l; gap_seen_at = n; gap_idle_poll = 0;
+                } else gap_idle_poll = n;
+                if ((double)(n - gap_seen_at) > g_stall_s * 1e9) {
                     fprintf(stderr, "loadgen: stalled at %llu/%llu lines for %.0f s\n", (unsigned long long)l,
                             (unsigned long long)g_expect_lines, g_stall_s);
                     timed_out = 1; break;
@@ -843,12 +897,34 @@ int main(int argc, char **argv) {
     printf("\"ack_latency_us\":{\"mean\":%.2f,\"p50\":%.2f,\"p99\":%.2f,\"max\":%.2f},",
            lat_mean / 1e3, nlat ? (double)lat[nlat / 2] / 1e3 : 0.0,
            nlat ? (double)lat[(size_t)((double)(nlat - 1) * 0.99)] / 1e3 : 0.0, nlat ? (double)lat[nlat - 1] / 1e3 : 0.0);
+    /* acknowledgements that took more than ten medians (and at least 1 ms over it): how many, and how much wall
+       clock they hold between them -- in a one-sender closed loop that is the stalled time itself */
+    {
+        double p50 = nlat ? (double)lat[nlat / 2] : 0.0, thr = p50 * 10.0 > p50 + 1e6 ? p50 * 10.0 : p50 + 1e6, tot = 0; size_t cnt = 0;
+        for (size_t i = nlat; i-- > 0 && (double)lat[i] > thr;) { cnt++; tot += (double)lat[i]; }
+        printf("\"slow_acks\":{\"threshold_us\":%.1f,\"count\":%zu,\"total_s\":%.6f},", thr / 1e3, cnt, tot / 1e9);
+    }
+    printf("\"progress_gaps\":{\"threshold_ms\":%.1f,\"count\":%u,\"total_s\":%.6f,\"max_ms\":%.3f},",
+           (double)GAP_NS / 1e6, gap_n, (double)gap_total / 1e9, (double)gap_max / 1e6);
+    printf("\"workers\":[");
+    for (int t = 0; t < g_nthreads; t++) {
+        struct worker *w = &g_workers[t]; int senders = 0;
+        for (int i = 0; i < w->ncl; i++) if (w->cl[i]->timed.n) senders++;
+        printf("%s{\"cpu\":%d,\"clients\":%d,\"senders\":%d,\"cpu_s\":%.6f,\"run_delay_s\":%.6f}", t ? "," : "", w->cpu, w->ncl, senders,
+               w->cpu1_ns > w->cpu0_ns ? (double)(w->cpu1_ns - w->cpu0_ns) / 1e9 : 0.0,
+               w->rq1_ns > w->rq0_ns ? (double)(w->rq1_ns - w->rq0_ns) / 1e9 : 0.0);
+    }
+    printf("],");
     printf("\"servers\":[");
     for (int i = 0; i < g_nservers; i++) {
-        printf("%s{\"pid\":%d,\"utime_s\":%.3f,\"stime_s\":%.3f,\"cpu_ns\":%llu,\"read_syscalls\":%llu,\"write_syscalls\":%llu,\"bytes_written\":%llu}",
+        printf("%s{\"pid\":%d,\"utime_s\":%.3f,\"stime_s\":%.3f,\"cpu_ns\":%llu,\"run_delay_ns\":%llu,"
+               "\"voluntary_switches\":%llu,\"involuntary_switches\":%llu,"
+               "\"read_syscalls\":%llu,\"write_syscalls\":%llu,\"bytes_written\":%llu}",
                i ? "," : "", g_server_pids[i],
                failed ? 0.0 : s1[i].utime_s - s0[i].utime_s, failed ? 0.0 : s1[i].stime_s - s0[i].stime_s,
                failed ? 0ull : (unsigned long long)(s1[i].sched_ns - s0[i].sched_ns),
+               (unsigned long long)(s1[i].rq_ns - s0[i].rq_ns),
+               (unsigned long long)(s1[i].vcsw - s0[i].vcsw), (unsigned long long)(s1[i].ivcsw - s0[i].ivcsw),
                (unsigned long long)(s1[i].syscr - s0[i].syscr), (unsigned long long)(s1[i].syscw - s0[i].syscw),
                (unsigned long long)(s1[i].wchar - s0[i].wchar));
     }

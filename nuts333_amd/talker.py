@@ -66,13 +66,17 @@ def free_ports(n: int = 3) -> list[int]:
 
 class Talker:
     def __init__(self, binary: os.PathLike | str, root: os.PathLike | str, config_name: str = "config",
-                 cpu: int | None = None, tz: str = "UTC", burn_fds: int = 0):
+                 cpu: int | None = None, tz: str = "UTC", burn_fds: int = 0, extra_env: dict[str, str] | None = None):
         self.binary = Path(binary)
         self.root = Path(root)
         self.config_name = config_name
         self.cpu = cpu
         self.tz = tz
         self.burn_fds = burn_fds     # tests only: start the daemon with this many descriptors already in use
+        # tests only: variables for THIS talker's environment (e.g. the LD_PRELOAD write-size logger).  Merged into the
+        # copy handed to Popen; os.environ is never touched, so a profiler's own LD_PRELOAD and every other child of the
+        # calling process are left alone.  An LD_PRELOAD given here is put in front of an inherited one.
+        self.extra_env = dict(extra_env or {})
         self.pid: int | None = None
 
     # -- lifecycle -------------------------------------------------------------------
@@ -85,6 +89,8 @@ class Talker:
         if syslog.exists():
             syslog.unlink()
         env = dict(os.environ, TZ=self.tz)
+        for k, v in self.extra_env.items():
+            env[k] = f"{v}:{env[k]}" if k == "LD_PRELOAD" and env.get(k) else v
         out = open(self.root / "boot.log", "wb")
 
         # No preexec_fn (unsafe when the parent has threads, e.g. after torch was imported): the new session comes

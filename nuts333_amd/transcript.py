@@ -461,8 +461,26 @@ class Session:
         # test relies on that) -- then one round of syncs collects it everywhere.  Nobody listening (a half-open login
         # closed, everyone ignoring): the wait times out and the round of syncs records the silence.
         listeners = [o.sock for o in others if o.logged_in]     # a half-open login dropped by the talker reads EOF for ever
-        if listeners:
-            select.select(listeners, [], [], 0.5)
+        # Content-aware, still passive: when the leaver was logged in, look (MSG_PEEK -- nothing is consumed, nothing
+        # is sent) for the broadcast itself for up to 5 s.  A talker descheduled for more than half a second on a busy
+        # host, or an unrelated byte from a netlink relay, must not end the wait early and push SIGN OFF into the next
+        # step's capture.  A half-open login leaves silently (nuts333.c:1770-1775): the short wait is enough there.
+        expect_broadcast = bool(listeners) and c.logged_in
+        deadline = time.monotonic() + (5.0 if expect_broadcast else 0.5)
+        seen = False
+        while listeners and not seen and time.monotonic() < deadline:
+            ready, _, _ = select.select(listeners, [], [], max(0.0, deadline - time.monotonic()))
+            if not expect_broadcast:
+                break
+            for sock in ready:
+                try:
+                    if b"SIGN OFF:" in sock.recv(65536, socket.MSG_PEEK):
+                        seen = True
+                        break
+                except OSError:
+                    pass
+            if ready and not seen:
+                time.sleep(0.005)       # bytes that are not the broadcast are pending: do not spin on them
         recv: dict[str, bytes] = self._collect(None) if others else {}
         self._record({"op": "close", "actor": key}, recv)
 

@@ -27,6 +27,7 @@ import tempfile
 from pathlib import Path
 from typing import Callable, Sequence
 
+from . import placement
 from . import provision as pv
 from .talker import PORT_BINARY, REF_BINARY, Talker, free_ports
 
@@ -56,7 +57,8 @@ def build_loadgen(force: bool = False) -> Path:
 
 
 def host_cpus() -> list[int]:
-    return sorted(os.sched_getaffinity(0))
+    """The cores this process places talkers and receivers on, the talker's first (see placement.py)."""
+    return placement.ordered_cpus()
 
 
 #: upper bound on busy-polling receiver threads per load-generator process; bench.py lowers it when several replicas
@@ -189,6 +191,7 @@ def run_spec(spec: Spec, talkers: Sequence[Talker], *, timeout_s: float = 600.0,
     res["deliveries"] -= spec.expected_self_extra        # the load generator counts "lines that are not acks"
     res["self_extra_lines"] = spec.expected_self_extra
     res["per_client_exact"] = res["per_client_lines"] == spec.expected_per_client
+    res["placement"] = {"talker_cpus": sorted(server_cpus), "receiver_cpus": client_cpus[:threads]}
     res["exact"] = bool(res["per_client_exact"] and res["lines_total"] == spec.expect_lines
                         and res["deliveries"] == spec.expected_deliveries)
     return summarise(res)
@@ -208,7 +211,57 @@ def summarise(res: dict) -> dict:
         s["busy_frac"] = s["cpu_ns"] / 1e9 / wall if wall > 0 else 0.0
         s["write_syscalls_per_line"] = s.get("write_syscalls", 0) / written if written else 0.0
         s["read_syscalls_per_input_line"] = s.get("read_syscalls", 0) / res["input_lines"] if res["input_lines"] else 0.0
+        # where the talker's wall clock went: on the CPU, runnable but kept off it, or asleep (select / a full socket)
+        s["run_delay_frac"] = s.get("run_delay_ns", 0) / 1e9 / wall if wall > 0 else 0.0
+        s["sleep_frac"] = max(0.0, 1.0 - s["busy_frac"] - s["run_delay_frac"])
+    for w in res.get("workers", []):
+        w["busy_frac"] = w["cpu_s"] / wall if wall > 0 else 0.0
     return res
+
+
+def leg_diagnostics(res: dict) -> dict:
+    """The fields that let one run explain its own wall clock: the talker's time split into
+    on-CPU / runnable-but-waiting / asleep, how long no line moved anywhere, how slow the slowest acknowledgements
+    were, and whether the (busy-polling) receiver threads were themselves kept off their cores."""
+    srv = res["servers"][0]
+    workers = res.get("workers", [])
+    sender_w = [w for w in workers if w.get("senders")] or workers
+    return {"wall_s": round(res["wall_s"], 4),
+            "server_busy_frac": round(srv["busy_frac"], 3),
+            "server_run_delay_frac": round(srv["run_delay_frac"], 4),
+            "server_sleep_frac": round(srv["sleep_frac"], 3),
+            "server_involuntary_switches": srv.get("involuntary_switches"),
+            "server_voluntary_switches": srv.get("voluntary_switches"),
+            "ack_latency_us": {k: res["ack_latency_us"][k] for k in ("p50", "p99", "max")},
+            "slow_acks": res.get("slow_acks"), "progress_gaps": res.get("progress_gaps"),
+            "receiver_busy_frac_min": round(min((w["busy_frac"] for w in workers), default=0.0), 3),
+            "sender_receiver_busy_frac": round(min((w["busy_frac"] for w in sender_w), default=0.0), 3),
+            "sender_receiver_run_delay_s": round(max((w["run_delay_s"] for w in sender_w), default=0.0), 4),
+            "placement": res.get("placement")}
+
+
+def attribute_stall(res: dict, *, saturating: bool = True, throttled_periods: int | None = None) -> str | None:
+    """None when the talker was the bottleneck, as a saturating configuration (#2-#4) expects; otherwise one sentence
+    saying where its idle time went, from the run's own counters."""
+    srv = res["servers"][0]
+    idle = 1.0 - srv["busy_frac"]
+    if not saturating or idle < 0.10:
+        return None
+    d = leg_diagnostics(res)
+    head = f"harness stall: talker busy only {srv['busy_frac']:.2f} of {res['wall_s']:.2f} s wall"
+    gaps = d["progress_gaps"] or {}
+    tail = (f"; no line moved anywhere for {gaps.get('total_s', 0):.2f} s in {gaps.get('count', 0)} gaps >= {gaps.get('threshold_ms', 5):.0f} ms "
+            f"(longest {gaps.get('max_ms', 0):.0f} ms); ack p50/max {d['ack_latency_us']['p50']:.0f}/{d['ack_latency_us']['max']:.0f} us")
+    if throttled_periods:
+        return f"{head} -- cgroup CPU quota throttled this container in {throttled_periods} periods{tail}"
+    if srv["run_delay_frac"] > idle / 2:
+        return (f"{head} -- it was RUNNABLE but off its core for {srv['run_delay_frac']:.2f} of the wall "
+                f"({srv.get('involuntary_switches')} involuntary switches): another tenant on CPU {d['placement']['talker_cpus']}{tail}")
+    if d["sender_receiver_busy_frac"] < 0.90:
+        return (f"{head} -- it was ASLEEP in select() while the sender's busy-polling receiver thread got only "
+                f"{d['sender_receiver_busy_frac']:.2f} of its core (run-queue wait {d['sender_receiver_run_delay_s']:.2f} s): "
+                f"the closed loop waited for the client, not the talker{tail}")
+    return f"{head} -- asleep for {srv['sleep_frac']:.2f} of the wall with its receivers running: unattributed{tail}"
 
 
 # --------------------------------------------------------------------------- configs

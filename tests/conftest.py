@@ -15,6 +15,7 @@ sys.path.insert(0, str(REPO / "tests"))
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box only)")
     config.addinivalue_line("markers", "reference: needs oracle/_ref/nuts333 (built where /root/reference exists)")
+    config.addinivalue_line("markers", "host_only: in a BOTH_TIERS module, run this test in the host tier only")
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -29,6 +30,10 @@ def tier(request):
 
 def pytest_generate_tests(metafunc):
     if getattr(metafunc.module, "BOTH_TIERS", False):
+        if metafunc.definition.get_closest_marker("host_only"):
+            # e.g. the restatement's NUTS_PORT_FAST mode: not a SURVEY section-8 row, no place in the box tier
+            metafunc.parametrize("tier", [pytest.param("host")], indirect=True)
+            return
         metafunc.parametrize("tier", [pytest.param("host"), pytest.param("gpubox", marks=pytest.mark.gpu)], indirect=True)
 
 

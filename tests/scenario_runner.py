@@ -53,21 +53,15 @@ def run_scenario(name: str, binaries: Path | Sequence[Path], writelog_shim: Path
             sess.peers[key] = Peer(key)
         cfgs = spec["configs"](ports, {k: p.port for k, p in sess.peers.items()}) if spec.get("peers") else spec["configs"](ports)
         try:
-            import os
             wlog = Path(tmp) / "writes.log"
-            if writelog_shim is not None:
-                os.environ.update(LD_PRELOAD=str(writelog_shim), WRITELOG=str(wlog))
-            try:
-                for i in spec["boot_order"]:
-                    root = Path(tmp) / f"t{i}"
-                    pv.write_tree(root, cfgs[i], spec["accounts"][i])
-                    for rel, content in spec.get("files", {}).items():
-                        (root / rel).write_text(content)
-                    talkers[i] = Talker(binaries[i], root)
-                    talkers[i].start()
-            finally:
-                if writelog_shim is not None:
-                    os.environ.pop("LD_PRELOAD", None); os.environ.pop("WRITELOG", None)
+            shim_env = {"LD_PRELOAD": str(writelog_shim), "WRITELOG": str(wlog)} if writelog_shim is not None else None
+            for i in spec["boot_order"]:
+                root = Path(tmp) / f"t{i}"
+                pv.write_tree(root, cfgs[i], spec["accounts"][i])
+                for rel, content in spec.get("files", {}).items():
+                    (root / rel).write_text(content)
+                talkers[i] = Talker(binaries[i], root, extra_env=shim_env)
+                talkers[i].start()
             for i, needle in spec.get("wait_syslog", []):
                 talkers[i].wait_syslog(needle)
             spec["script"](sess)

@@ -52,6 +52,7 @@ def test_port_matches_golden(name, port_binary):
     assert got.get("files") == gold.get("files")
 
 
+@pytest.mark.host_only
 @pytest.mark.parametrize("name", NAMES)
 def test_port_fast_mode_puts_the_same_bytes_on_the_wire(name, port_binary, monkeypatch):
     """NUTS_PORT_FAST=1 (transduce once per colour variant, reset merged into the same write, TCP_NODELAY on
