@@ -8,7 +8,7 @@ every other harness that "pins to the first core" lands too.  The one stalled le
 restatement at equal CPU per line and 5.3x the wall clock) had nothing in its record to say
 whether the talker was runnable and kept off its core or asleep waiting for a descheduled sender.
 
-So: sample ``/proc/stat`` for a quarter of a second, group the allowed CPUs by shared L3 (one CCD: the talker and
+So: sample ``/proc/stat`` for half a second, group the allowed CPUs by shared L3 (one CCD: the talker and
 its receivers must share it), drop SMT siblings, and take the quietest cores of the quietest group -- talker on the
 quietest one.  The choice and the idleness it was based on go into the result line.  ``NUTS_BENCH_CPUS=first``
 restores the old rule; no sysfs topology (a VM, a container without /sys) falls back to it as well.
@@ -67,7 +67,7 @@ def topology(cpus: list[int]) -> tuple[dict[int, int], dict[int, int]] | None:
     return l3, core
 
 
-def choose(n_wanted: int = 8, *, groups: int = 1, interval: float = 0.25) -> dict:
+def choose(n_wanted: int = 8, *, groups: int = 1, interval: float = 0.5) -> dict:
     """Pick ``groups`` disjoint sets of up to ``n_wanted`` cores.  Returns
     ``{"policy", "sets": [[talker_cpu, client_cpu, ...], ...], "busy_before": {cpu: frac}, "note"}``."""
     allowed = sorted(os.sched_getaffinity(0))

@@ -228,6 +228,9 @@ def leg_diagnostics(res: dict) -> dict:
     sender_w = [w for w in workers if w.get("senders")] or workers
     return {"wall_s": round(res["wall_s"], 4),
             "server_busy_frac": round(srv["busy_frac"], 3),
+            # busy 1.0 and still slow = the core itself was slower (a neighbour on the sibling thread or in the L3): it
+            # shows here, in the cost of a line, not in the scheduler's counters
+            "server_cpu_us_per_written_line": round(srv["cpu_us_per_written_line"], 3),
             "server_run_delay_frac": round(srv["run_delay_frac"], 4),
             "server_sleep_frac": round(srv["sleep_frac"], 3),
             "server_involuntary_switches": srv.get("involuntary_switches"),

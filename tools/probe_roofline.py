@@ -10,7 +10,8 @@ For the two fan-out shapes of the BASELINE configurations -- 10 clients / `say` 
   full_closed         1 select(FD_SETSIZE) + 1 read + K+1 writes, closed loop   -> peak from CPU time
   full_open           the same, open loop (select never sleeps)                 -> peak DEMONSTRATED on the wall clock
 
-and prints the medians.  bench.py's ``roofline.peak`` is min(full_closed CPU-time rate, full_open wall rate).
+and prints the medians.  As in bench.py, ``peak`` is the highest wall-clock rate any repetition of a full leg demonstrated;
+the closed loop's CPU-time extrapolation is ``peak_extrapolated`` (round 2 quoted the lower of the two medians).
 """
 from __future__ import annotations
 
@@ -39,10 +40,11 @@ def main() -> int:
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     workloads.build_loadgen()
-    cpus = sorted(os.sched_getaffinity(0))
+    cpus = workloads.host_cpus()          # quiet-core placement, as in bench.py (nuts333_amd/placement.py)
     readers = max(1, min(4, len(cpus) - 1))
     place = [str(cpus[0]), ",".join(map(str, cpus[1:1 + readers]))] if len(cpus) >= 2 else []
-    doc = {"host": host_info(), "reps": args.reps, "readers": readers, "placement": place, "shapes": {}}
+    from nuts333_amd import placement
+    doc = {"host": host_info(), "reps": args.reps, "readers": readers, "placement": place, "placement_policy": placement.describe(), "shapes": {}}
     for shape, (size, k) in SHAPES.items():
         rounds = max(100, 300_000 // (k + 1))
         legs = {}
@@ -51,16 +53,18 @@ def main() -> int:
             for _ in range(args.reps):
                 cmd = [str(workloads.LOADGEN_BIN), "--probe-line", str(size), str(k), str(rounds), str(selread), str(open_loop),
                        str(readers)] + place
-                runs.append(json.loads(subprocess.run(cmd, check=True, stdout=subprocess.PIPE).stdout))
+                runs.append(json.loads(subprocess.run(cmd, check=True, stdout=subprocess.PIPE, timeout=120).stdout))
             assert all(r["bytes_ok"] for r in runs)
             legs[leg] = {**{key: round(statistics.median(r[key] for r in runs), 1) for key in KEYS},
                          "written_lines_per_s_wall_all": [r["written_lines_per_s_wall"] for r in runs],
                          "written_lines_per_s_cpu_all": [r["written_lines_per_s_cpu"] for r in runs]}
         peak_cpu, peak_demo = legs["full_closed"]["written_lines_per_s_cpu"], legs["full_open"]["written_lines_per_s_wall"]
+        peak = max(legs["full_open"]["written_lines_per_s_wall_all"] + legs["full_closed"]["written_lines_per_s_wall_all"])
         doc["shapes"][shape] = {"bytes": size, "recipients": k, "writes_per_input_line": k + 1, "rounds": rounds, "legs": legs,
+                                "peak": peak, "peak_extrapolated": peak_cpu, "peak_demonstrated_median_open_loop": peak_demo,
                                 "peak_closed_loop_cpu_time": peak_cpu, "peak_open_loop_wall_demonstrated": peak_demo,
-                                "peak": min(peak_cpu, peak_demo), "peak_write_only": legs["write_only_closed"]["written_lines_per_s_cpu"]}
-        print(f"{shape}: peak {min(peak_cpu, peak_demo):,.0f} lines/s (CPU-time {peak_cpu:,.0f}, demonstrated {peak_demo:,.0f}; "
+                                "peak_write_only": legs["write_only_closed"]["written_lines_per_s_cpu"]}
+        print(f"{shape}: peak {peak:,.0f} lines/s demonstrated (open-loop median {peak_demo:,.0f}; CPU-time extrapolation {peak_cpu:,.0f}; "
               f"write-only {legs['write_only_closed']['written_lines_per_s_cpu']:,.0f}); select+read "
               f"{legs['full_closed']['cpu_ns_select_read_per_line'] / 1e3:.2f} us per input line, "
               f"{legs['full_closed']['cpu_ns_per_write'] / 1e3:.3f} us per write")
