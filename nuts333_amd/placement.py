@@ -6,7 +6,8 @@ round 2: a neighbour on the talker's core moves a run by 5-30 %).  Rounds 1-2 pi
 of the affinity set -- CPU 0 on the MI355X box, whose 256 CPUs are schedulable by every tenant of the host and where
 every other harness that "pins to the first core" lands too.  The one stalled leg of round 2's driver run (the
 restatement at equal CPU per line and 5.3x the wall clock) had nothing in its record to say
-whether the talker was runnable and kept off its core or asleep waiting for a descheduled sender.
+whether the talker was runnable and kept off its core or asleep waiting for a descheduled sender.  (Measured afterwards
+on the box, 12 + 12 interleaved runs: CPU 0 is not systematically worse -- profiles/stall_hunt_r03_*; this is a precaution.)
 
 So: sample ``/proc/stat`` for half a second, group the allowed CPUs by shared L3 (one CCD: the talker and
 its receivers must share it), drop SMT siblings, and take the quietest cores of the quietest group -- talker on the
