@@ -462,7 +462,7 @@ def test_stall_attribution_from_a_runs_own_counters():
                 "progress_gaps": {"threshold_ms": 5.0, "count": 40, "total_s": gaps_s, "max_ms": 200.0},
                 "placement": {"talker_cpus": [0], "receiver_cpus": [1, 2, 3, 4]},
                 "servers": [{"busy_frac": busy, "run_delay_frac": run_delay, "sleep_frac": max(0.0, 1 - busy - run_delay),
-                             "involuntary_switches": 999, "voluntary_switches": 5}],
+                             "involuntary_switches": 999, "voluntary_switches": 5, "cpu_us_per_written_line": 1.43}],
                 "workers": [{"senders": 1, "busy_frac": sender_busy, "run_delay_s": (1 - sender_busy) * wall, "cpu_s": sender_busy * wall},
                             {"senders": 0, "busy_frac": 1.0, "run_delay_s": 0.0, "cpu_s": wall}]}
     assert workloads.attribute_stall(run(0.97, 0.01, 1.0)) is None
