@@ -79,7 +79,7 @@ struct worker {
     int cpu;
     /* this thread over the timed window: CPU time it got and time it sat runnable on a run queue.  The workers
        busy-poll, so cpu/wall < 1 means the thread was descheduled (a neighbour on its core, or a cgroup throttle) */
-    uint64_t cpu0_ns, cpu1_ns, rq0_ns, rq1_ns;
+    uint64_t cpu0_ns, cpu1_ns, rq0_ns, rq1_ns, w0_ns, w1_ns;   /* thread CPU, run-queue wait and wall clock at both ends of the timed window */
 };
 
 static struct client *g_clients; static int g_nclients, g_capclients;
@@ -467,7 +467,7 @@ static void *worker_main(void *arg) {
             pthread_barrier_wait(&g_run_barrier);   /* main records t0 then joins */
             pthread_barrier_wait(&g_run_barrier);
             started_run = 1;
-            w->cpu0_ns = thread_cpu_ns(); w->rq0_ns = schedstat_run_delay("/proc/thread-self/schedstat");
+            w->cpu0_ns = thread_cpu_ns(); w->rq0_ns = schedstat_run_delay("/proc/thread-self/schedstat"); w->w0_ns = now_ns();
             for (int i = 0; i < w->ncl; i++) send_next(w->cl[i]);
             continue;
         }
@@ -489,9 +489,14 @@ static void *worker_main(void *arg) {
                     atomic_store(&g_t_end, now_ns());
             }
             if (!w->cpu1_ns && atomic_load(&g_done)) {
-                w->cpu1_ns = thread_cpu_ns(); w->rq1_ns = schedstat_run_delay("/proc/thread-self/schedstat");
+                w->cpu1_ns = thread_cpu_ns(); w->rq1_ns = schedstat_run_delay("/proc/thread-self/schedstat"); w->w1_ns = now_ns();
             }
         }
+    }
+    /* a worker that got no loop turn between g_done and the stop (descheduled through the grace period, or asleep in a
+       5 ms epoll_wait with spin 0) still reports its counters: sampled here, over the longer window it really covers */
+    if (w->cpu0_ns && !w->cpu1_ns) {
+        w->cpu1_ns = thread_cpu_ns(); w->rq1_ns = schedstat_run_delay("/proc/thread-self/schedstat"); w->w1_ns = now_ns();
     }
     free(rbuf);
     return NULL;
@@ -888,7 +893,7 @@ int main(int argc, char **argv) {
     if (nlat) lat_mean /= (double)nlat;
 
     double wall = (double)(t1 - t0) / 1e9;
-    printf("{\"ok\":%s,\"timed_out\":%d,\"clients\":%d,\"threads\":%d,", (failed || timed_out) ? "false" : "true", timed_out, g_nclients, g_nthreads);
+    printf("{\"ok\":%s,\"timed_out\":%d,\"clients\":%d,\"threads\":%d,\"spin\":%d,", (failed || timed_out) ? "false" : "true", timed_out, g_nclients, g_nthreads, g_spin);
     printf("\"planned_input_lines\":%llu,\"input_lines\":%llu,\"acks\":%llu,", (unsigned long long)planned, (unsigned long long)sent, (unsigned long long)acks);
     printf("\"lines_total\":%llu,\"expected_lines\":%llu,\"deliveries\":%llu,\"bytes_total\":%llu,",
            (unsigned long long)lines, (unsigned long long)g_expect_lines,
@@ -910,9 +915,10 @@ int main(int argc, char **argv) {
     for (int t = 0; t < g_nthreads; t++) {
         struct worker *w = &g_workers[t]; int senders = 0;
         for (int i = 0; i < w->ncl; i++) if (w->cl[i]->timed.n) senders++;
-        printf("%s{\"cpu\":%d,\"clients\":%d,\"senders\":%d,\"cpu_s\":%.6f,\"run_delay_s\":%.6f}", t ? "," : "", w->cpu, w->ncl, senders,
+        printf("%s{\"cpu\":%d,\"clients\":%d,\"senders\":%d,\"cpu_s\":%.6f,\"run_delay_s\":%.6f,\"window_s\":%.6f}", t ? "," : "", w->cpu, w->ncl, senders,
                w->cpu1_ns > w->cpu0_ns ? (double)(w->cpu1_ns - w->cpu0_ns) / 1e9 : 0.0,
-               w->rq1_ns > w->rq0_ns ? (double)(w->rq1_ns - w->rq0_ns) / 1e9 : 0.0);
+               w->rq1_ns > w->rq0_ns ? (double)(w->rq1_ns - w->rq0_ns) / 1e9 : 0.0,
+               w->w1_ns > w->w0_ns ? (double)(w->w1_ns - w->w0_ns) / 1e9 : 0.0);
     }
     printf("],");
     printf("\"servers\":[");

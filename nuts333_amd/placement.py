@@ -21,6 +21,8 @@ import time
 from pathlib import Path
 
 _SYS = Path("/sys/devices/system/cpu")
+#: what one replica can put to use: 1 talker + 4 receiver threads (workloads.MAX_CLIENT_THREADS) + config #5's second talker
+NEED_CPUS = 6
 _cached: dict | None = None
 
 
@@ -109,9 +111,22 @@ def choose(n_wanted: int = 8, *, groups: int = 1, interval: float = 0.5) -> dict
     scored.sort(key=lambda t: (round(t[0], 2), t[1], t[2]))
     sets = [[e["cpu"] for e in t[3]] for t in scored[:groups]]
     used = {c for s in sets for c in s}
+    # one thread per core of ONE L3 group can be too few on a small SMT host (2 cores / 4 threads -> talker + 1
+    # receiver, which is client-bound, and no core at all for config #5's second talker): top such a set up with the
+    # quietest remaining CPUs, sibling threads and cores of the same group first
+    need = min(per, NEED_CPUS)
+    topped = 0
+    for s in sets:
+        spare = sorted((c for c in allowed if c not in used), key=lambda c: (l3[c] != l3[s[0]], round(busy.get(c, 0.0), 2), c))
+        while len(s) < need and spare:
+            c = spare.pop(0)
+            s.append(c)
+            used.add(c)
+            topped += 1
     return {"policy": "quiet", "sets": sets, "busy_before": {str(c): round(busy.get(c, 0.0), 3) for c in sorted(used)},
             "note": f"quietest {groups} of {len(scored)} L3 groups over a {interval:.2f}s /proc/stat sample; one thread per core; "
-                    "talker on the first CPU of its set"}
+                    "talker on the first CPU of its set"
+                    + (f"; topped up with {topped} sibling/neighbouring CPU(s) to reach {need} per set" if topped else "")}
 
 
 def ordered_cpus(refresh: bool = False) -> list[int]:

@@ -61,6 +61,7 @@ class Client:
     can_sync: bool = True          # False while in a state where .version is not interpreted
     sync_suffix: bytes = b""       # bytes a prompt adds after every command reply (command mode)
     prompt_re: bytes = b""         # regex source for a clock-bearing prompt (prompt on, speech mode)
+    hears_broadcasts: bool = True  # False while the user has .ignall on (write_room skips it, nuts333.c:1413)
     buf: bytearray = field(default_factory=bytearray)
 
     def read_until(self, suffix_or_pred, timeout: float = 10.0) -> bytes:
@@ -342,6 +343,8 @@ class Session:
         the given suffix instead."""
         c = self.clients[key]
         c.send_raw(text.encode("latin-1") + b"\n")
+        if text.strip() == ".ignall" and c.logged_in:          # a toggle (nuts333.c:5655-5667); only close()'s wait reads it
+            c.hears_broadcasts = not c.hears_broadcasts
         if flags:
             self.set_flags(key, **flags)
         if expect is not None:
@@ -439,8 +442,10 @@ class Session:
         time.sleep(quiet)
 
     def set_flags(self, key: str, *, colour: bool | None = None, can_sync: bool | None = None,
-                  sync_suffix: bytes | None = None, prompt_re: bytes | None = None) -> None:
+                  sync_suffix: bytes | None = None, prompt_re: bytes | None = None, hears_broadcasts: bool | None = None) -> None:
         c = self.clients[key]
+        if hears_broadcasts is not None:
+            c.hears_broadcasts = hears_broadcasts
         if colour is not None:
             c.colour = colour
         if can_sync is not None:
@@ -460,11 +465,16 @@ class Session:
         # that the talker's own sequence of write(2) calls is a function of the script alone (the write-order parity
         # test relies on that) -- then one round of syncs collects it everywhere.  Nobody listening (a half-open login
         # closed, everyone ignoring): the wait times out and the round of syncs records the silence.
-        listeners = [o.sock for o in others if o.logged_in]     # a half-open login dropped by the talker reads EOF for ever
+        # Only listeners the broadcast can reach are waited on: logged in (a half-open login dropped by the talker
+        # reads EOF for ever) and not ignoring everything (write_room skips ignall users, nuts333.c:1413; the editor sets the
+        # same skip but no script closes a peer while another is in it).  Listeners on the OTHER talker of a linked pair stay
+        # in: write_room(NULL, ...) at nuts333.c:1782 also reaches REMOTE_TYPE users, whose copy travels over the link.
+        listeners = [o.sock for o in others if o.logged_in and o.hears_broadcasts]
         # Content-aware, still passive: when the leaver was logged in, look (MSG_PEEK -- nothing is consumed, nothing
         # is sent) for the broadcast itself for up to 5 s.  A talker descheduled for more than half a second on a busy
         # host, or an unrelated byte from a netlink relay, must not end the wait early and push SIGN OFF into the next
-        # step's capture.  A half-open login leaves silently (nuts333.c:1770-1775): the short wait is enough there.
+        # step's capture.  A half-open login leaves silently (nuts333.c:1770-1775): the short wait is enough there, and so
+        # it is when nobody is left who could be sent the broadcast.
         expect_broadcast = bool(listeners) and c.logged_in
         deadline = time.monotonic() + (5.0 if expect_broadcast else 0.5)
         seen = False
@@ -474,12 +484,17 @@ class Session:
                 break
             for sock in ready:
                 try:
-                    if b"SIGN OFF:" in sock.recv(65536, socket.MSG_PEEK):
-                        seen = True
-                        break
+                    peeked = sock.recv(65536, socket.MSG_PEEK)
                 except OSError:
-                    pass
-            if ready and not seen:
+                    peeked = b""
+                if b"SIGN OFF:" in peeked:
+                    seen = True
+                    break
+                if not peeked:          # EOF (or a dead socket) stays select()-ready for ever: stop waiting on it
+                    listeners.remove(sock)
+            if not listeners and not seen:          # nobody left to hear it: what remains is the short, silent wait
+                time.sleep(max(0.0, min(0.5, deadline - time.monotonic())))
+            elif ready and not seen:
                 time.sleep(0.005)       # bytes that are not the broadcast are pending: do not spin on them
         recv: dict[str, bytes] = self._collect(None) if others else {}
         self._record({"op": "close", "actor": key}, recv)

@@ -215,7 +215,9 @@ def summarise(res: dict) -> dict:
         s["run_delay_frac"] = s.get("run_delay_ns", 0) / 1e9 / wall if wall > 0 else 0.0
         s["sleep_frac"] = max(0.0, 1.0 - s["busy_frac"] - s["run_delay_frac"])
     for w in res.get("workers", []):
-        w["busy_frac"] = w["cpu_s"] / wall if wall > 0 else 0.0
+        # each worker's own sampling window (it ends a loop turn after the run's, later still for a descheduled one)
+        span = w.get("window_s") or wall
+        w["busy_frac"] = w["cpu_s"] / span if span > 0 else 0.0
     return res
 
 
@@ -243,9 +245,13 @@ def leg_diagnostics(res: dict) -> dict:
             "placement": res.get("placement")}
 
 
-def attribute_stall(res: dict, *, saturating: bool = True, throttled_periods: int | None = None) -> str | None:
+def attribute_stall(res: dict, *, saturating: bool = True, throttled_periods: int | None = None,
+                    throttled_ms: float | None = None) -> str | None:
     """None when the talker was the bottleneck, as a saturating configuration (#2-#4) expects; otherwise one sentence
-    saying where its idle time went, from the run's own counters."""
+    saying where its idle time went, from the run's own counters.  The cgroup's throttle counters are taken around the
+    WHOLE leg (boot, logins, drain, warm-up, timed window), so they are blamed first only when they can plausibly account
+    for the window's idle time -- throttled for at least half of it, or the talker itself shows run-queue wait; otherwise
+    they follow the counter-based attribution as context."""
     srv = res["servers"][0]
     idle = 1.0 - srv["busy_frac"]
     if not saturating or idle < 0.10:
@@ -256,11 +262,16 @@ def attribute_stall(res: dict, *, saturating: bool = True, throttled_periods: in
     tail = (f"; no line moved anywhere for {gaps.get('total_s', 0):.2f} s in {gaps.get('count', 0)} gaps >= {gaps.get('threshold_ms', 5):.0f} ms "
             f"(longest {gaps.get('max_ms', 0):.0f} ms); ack p50/max {d['ack_latency_us']['p50']:.0f}/{d['ack_latency_us']['max']:.0f} us")
     if throttled_periods:
-        return f"{head} -- cgroup CPU quota throttled this container in {throttled_periods} periods{tail}"
+        quota = f"cgroup CPU quota throttled this container in {throttled_periods} periods" + (
+            f" ({throttled_ms:.0f} ms)" if throttled_ms is not None else "")
+        if srv["run_delay_frac"] > 0.01 or (throttled_ms is not None and throttled_ms / 1e3 >= idle * res["wall_s"] / 2):
+            return f"{head} -- {quota}{tail}"
+        tail += f"; context: {quota} somewhere in the leg (boot and logins included), too little to explain the window"
     if srv["run_delay_frac"] > idle / 2:
         return (f"{head} -- it was RUNNABLE but off its core for {srv['run_delay_frac']:.2f} of the wall "
                 f"({srv.get('involuntary_switches')} involuntary switches): another tenant on CPU {d['placement']['talker_cpus']}{tail}")
-    if d["sender_receiver_busy_frac"] < 0.90:
+    # (workers only busy-poll under `spin 1`: with spin 0 a low busy fraction is the design, not a symptom)
+    if res.get("spin", 1) and d["sender_receiver_busy_frac"] < 0.90:
         return (f"{head} -- it was ASLEEP in select() while the sender's busy-polling receiver thread got only "
                 f"{d['sender_receiver_busy_frac']:.2f} of its core (run-queue wait {d['sender_receiver_run_delay_s']:.2f} s): "
                 f"the closed loop waited for the client, not the talker{tail}")

@@ -7,7 +7,7 @@ the record to say why.  This repeats exactly that sequence -- three probe legs, 
 lines to 999 recipients -- REPS times, alternating the old placement (``first``: CPU 0 + 1-4) and the round-3
 placement (``quiet``: the quietest L3 group), and prints for every run where the talker's wall clock went.
 
-    python tools/stall_hunt.py [REPS] > gpurun_out/stall_hunt.log
+    python profiles/stall_hunt_r03_experiment.py [REPS] > gpurun_out/stall_hunt.log
 """
 from __future__ import annotations
 

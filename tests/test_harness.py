@@ -12,6 +12,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 from pathlib import Path
 
 import pytest
@@ -69,6 +70,35 @@ def test_both_talkers_accept_the_generated_tree(tmp_path, port_binary):
         with Talker(b, root) as t:
             assert t.alive() and t.pid > 0
         assert not t.alive()
+
+
+def test_close_does_not_wait_for_a_broadcast_nobody_will_be_sent(tmp_path, port_binary):
+    """the content-aware wait in Session.close() looks for 'SIGN OFF:' for up to 5 s.  With the only listener
+    ignoring everything (write_room skips it, nuts333.c:1413) it used to sit out the whole 5 s; a listener that CAN hear it
+    still ends the wait at once, with the broadcast in the step's capture."""
+    import time
+    from nuts333_amd.transcript import Session
+    ports = free_ports(3)
+    root = pv.write_tree(tmp_path / "t", pv.TalkerConfig(mainport=ports[0], wizport=ports[1], linkport=ports[2]),
+                         [pv.Account("Alice"), pv.Account("Bobby"), pv.Account("Carol")])
+    with Talker(port_binary, root):
+        s = Session(ports[0])
+        try:
+            for k, n in (("a", "Alice"), ("b", "Bobby")):
+                s.connect(k); s.login(k, n)
+            s.line("b", ".ignall")
+            assert s.clients["b"].hears_broadcasts is False
+            t = time.monotonic()
+            s.close("a")
+            assert time.monotonic() - t < 2.5 and "SIGN OFF" not in s.steps[-1]["recv"].get("b", "")
+            s.line("b", ".ignall")
+            assert s.clients["b"].hears_broadcasts is True
+            s.connect("c"); s.login("c", "Carol")
+            t = time.monotonic()
+            s.close("c")
+            assert time.monotonic() - t < 2.5 and "SIGN OFF: Carol" in s.steps[-1]["recv"]["b"]
+        finally:
+            s.shutdown()
 
 
 def test_restatement_survives_the_fd_setsize_cliff(tmp_path, port_binary):
@@ -356,16 +386,35 @@ CONTRACT_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
 
 
-def _bench(*args, env=None):
-    out = subprocess.run([sys.executable, str(REPO / "bench.py"), *args], check=True, stdout=subprocess.PIPE,
-                         env={**os.environ, **(env or {})}, timeout=600).stdout.decode().strip().splitlines()
-    assert len(out) == 1, out
-    return json.loads(out[0])
+def _bench(*args, env=None, full=False):
+    """One bench.py run -> its stdout line (the compact record); with ``full`` also the full record it wrote beside it."""
+    with tempfile.TemporaryDirectory() as tmp:
+        record = Path(tmp) / "full.json"
+        out = subprocess.run([sys.executable, str(REPO / "bench.py"), *args], check=True, stdout=subprocess.PIPE,
+                             env={**os.environ, "NUTS_BENCH_FULL_RECORD": str(record), **(env or {})},
+                             timeout=900).stdout.decode().strip().splitlines()
+        assert len(out) == 1, out
+        j = json.loads(out[0])
+        # the driver's record keeps ~8 KB of stdout+stderr tail: the line must fit whole (round 3's 12 KB line did not)
+        assert len(out[0]) <= 6000, len(out[0])
+        if not full:
+            return j
+        assert j["full_record"] == str(record)
+        return j, json.loads(record.read_text())
 
 
 def test_bench_single_replica_contract():
-    j = _bench("--steps", "2", "--warmup", "1", "--lines-per-step", "200", "--binary", "port", "--workload", "config2")
-    assert CONTRACT_KEYS <= set(j)
+    line, j = _bench("--steps", "2", "--warmup", "1", "--lines-per-step", "200", "--binary", "port", "--workload", "config2", full=True)
+    assert CONTRACT_KEYS <= set(line) and CONTRACT_KEYS <= set(j)
+    # the compact line copies, never recomputes: every figure it carries is the full record's
+    for k in ("value", "ms_per_step", "delivered", "expected_delivered", "cpu_baseline", "warnings", "configs_all_exact", "extras_errors"):
+        assert line[k] == j[k], k
+    assert {k: v for k, v in line["roofline"].items() if k not in ("note", "unit", "demonstrated_wall_all")} == \
+           {k: v for k, v in j["roofline"].items() if k not in ("note", "unit", "probe")}
+    assert line["roofline"]["demonstrated_wall_all"]["open"] == j["roofline"]["probe"]["full_open"]["written_lines_per_s_wall_all"]
+    assert [(c["name"], c["delivered_lines_per_s"], c["exact"], c["rate_all_reps"]) for c in line["configs"]] == \
+           [(c["name"], c["delivered_lines_per_s"], c["exact"], c["rate_all_reps"]) for c in j["configs"]]
+    assert line["host"]["loadavg_before_run"] == j["host"]["loadavg_before_run"] and "note" in line["configs"][3]
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["gpu_used"] is False
     assert j["delivered"] == j["expected_delivered"] == 2 * 200 * 9
     assert j["vs_baseline"] is None and j["scaling"] == "weak" and j["higher_is_better"] is True
@@ -388,9 +437,14 @@ def test_bench_single_replica_contract():
     assert "model" not in j["config"] and "workload" in j["config"]
     # every BASELINE configuration is in the same line, exact, with measured link frames for #5
     names = [c["name"] for c in j["configs"]]
-    assert names == ["config1", "config2", "config3", "config4", "config5"] and j["configs_all_exact"] and j["extras_errors"] == []
-    assert [c["n"] for c in j["configs"]] == [1, 10, 100, 1000, 20] and [c["reps"] for c in j["configs"]] == [3, 3, 3, 3, 1]
-    assert j["configs"][4]["netlink"]["writes_t2_to_t1"] == 11000 and j["configs"][4]["netlink"]["writes_t1_to_t2"] == 1000
+    assert names == ["config1", "config2", "config3", "config3_six_rooms", "config4", "config5"]
+    assert j["configs_all_exact"] and j["extras_errors"] == []
+    assert [c["n"] for c in j["configs"]] == [1, 10, 100, 100, 1000, 20] and [c["reps"] for c in j["configs"]] == [3, 3, 3, 3, 3, 1]
+    # BASELINE.json's "all 6 rooms" and the shipped five, side by side at the formal size, each saying which it is
+    five, six = j["configs"][2], j["configs"][3]
+    assert "over 5 rooms" in five["workload"] and "over 6 rooms" in six["workload"] and "datafiles/config:34-39" in five["note"]
+    assert six["input_lines"] == five["input_lines"] == 20000 and six["delivered"] != five["delivered"]
+    assert j["configs"][5]["netlink"]["writes_t2_to_t1"] == 11000 and j["configs"][5]["netlink"]["writes_t1_to_t2"] == 1000
 
 
 def test_bench_extras_cannot_cost_the_result_line(monkeypatch):
@@ -420,23 +474,24 @@ def test_bench_extras_cannot_cost_the_result_line(monkeypatch):
             return None
 
     out = bench.all_configs(Path("x"), True, "config4", fake(8.0, 1000), attempt, headline_size=(1000, 20))
-    assert [e["name"] for e in out] == ["config1", "config2", "config3", "config4", "config5"]
+    assert [e["name"] for e in out] == ["config1", "config2", "config3", "config3_six_rooms", "config4", "config5"]
     assert out[0]["delivered_lines_per_s"] == 200.0 and out[0]["rate_all_reps"] == [300.0, 100.0, 200.0]     # the median run
     assert out[1]["exact"] is False and "error" in out[1] and len(errors) == 3
-    assert out[3]["includes_headline_run"] and out[3]["reps"] == 3 and out[3]["rate_all_reps"] == [8.0, 7.0, 7.0]
-    assert out[4]["exact"] and out[4]["netlink"] == {"exact": True}
+    assert out[4]["includes_headline_run"] and out[4]["reps"] == 3 and out[4]["rate_all_reps"] == [8.0, 7.0, 7.0]
+    assert out[5]["exact"] and out[5]["netlink"] == {"exact": True}
     # a timed run of another size (--steps 5, --lines-per-step ...) is NOT one of the formal-size repetitions
     errors.clear()
     for size in ((500, 100), None):
         other = bench.all_configs(Path("x"), True, "config4", fake(8.0, 1000), attempt, headline_size=size)
-        assert other[3]["includes_headline_run"] is False and other[3]["reps"] == 3 and other[3]["rate_all_reps"] == [7.0, 7.0, 7.0]
+        assert other[4]["includes_headline_run"] is False and other[4]["reps"] == 3 and other[4]["rate_all_reps"] == [7.0, 7.0, 7.0]
 
 
-def test_bench_exit_code_is_nonzero_when_a_configuration_is_inexact(monkeypatch, capsys, port_binary):
+def test_bench_exit_code_is_nonzero_when_a_configuration_is_inexact(monkeypatch, capsys, port_binary, tmp_path):
     """the line still prints (fault-tolerant extras), but a driver that reads only the exit code
     learns that the record is not exact."""
     sys.path.insert(0, str(REPO))
     import bench
+    monkeypatch.setenv("NUTS_BENCH_FULL_RECORD", str(tmp_path / "full.json"))
     real = workloads.config2(lines=60, warmup=5, binary=port_binary)
     assert real["exact"]
     monkeypatch.setattr(bench, "run_workload", lambda *a, **kw: dict(real))
@@ -472,6 +527,106 @@ def test_stall_attribution_from_a_runs_own_counters():
     assert "ASLEEP in select()" in msg and "0.15 of its core" in msg and "8.00 s in 40 gaps" in msg
     assert "throttled this container in 7 periods" in workloads.attribute_stall(run(0.19, 0.80, 1.0), throttled_periods=7)
     assert "unattributed" in workloads.attribute_stall(run(0.19, 0.0, 1.0))
+
+
+def test_throttling_is_blamed_first_only_when_it_can_explain_the_window():
+    """the cgroup counters are taken around the whole leg (boot + 1000 logins + warm-up + window); one throttled
+    period during login must not label a window whose talker shows no run-queue wait."""
+    def run(run_delay, sender_busy):
+        return {"wall_s": 10.0, "spin": 1, "ack_latency_us": {"p50": 1300.0, "p99": 1400.0, "max": 250000.0}, "slow_acks": None,
+                "progress_gaps": {"threshold_ms": 5.0, "count": 4, "total_s": 1.0, "max_ms": 200.0},
+                "placement": {"talker_cpus": [0], "receiver_cpus": [1]},
+                "servers": [{"busy_frac": 0.2, "run_delay_frac": run_delay, "sleep_frac": 0.8 - run_delay, "involuntary_switches": 3,
+                             "voluntary_switches": 5, "cpu_us_per_written_line": 1.4}],
+                "workers": [{"senders": 1, "busy_frac": sender_busy, "run_delay_s": 8.0, "cpu_s": 1.5}]}
+    msg = workloads.attribute_stall(run(0.0, 0.15), throttled_periods=1, throttled_ms=12.0)
+    assert "ASLEEP in select()" in msg and "context: cgroup CPU quota throttled this container in 1 periods (12 ms)" in msg
+    assert " -- cgroup CPU quota throttled" in workloads.attribute_stall(run(0.0, 0.15), throttled_periods=60, throttled_ms=5000.0)
+    assert " -- cgroup CPU quota throttled" in workloads.attribute_stall(run(0.3, 1.0), throttled_periods=2, throttled_ms=10.0)
+    # workers that do not busy-poll (spin 0) are never blamed for being idle
+    quiet = {**run(0.0, 0.15), "spin": 0}
+    assert "unattributed" in workloads.attribute_stall(quiet)
+
+
+def test_client_bound_replicas_say_so_in_the_line():
+    """8 replicas under the 1-GPU box's 16-core quota get int(16/8 - 1.5) = 0 -> 1 receiver thread each,
+    which DESIGN.md section 5's sweep calls client-bound: the line must carry that, in the words the review asked for."""
+    sys.path.insert(0, str(REPO))
+    import bench
+    assert max(1, min(4, int(16.0 / 8 - 1.5))) == 1 and max(1, min(4, int(16.0 / 4 - 1.5))) == 2      # bench.main's arithmetic
+    w = bench.client_bound_warning("config4", 8, 16.0, 1, 256)
+    assert "8 replica(s) under a 16-core quota leave 1 receiver thread each: client-bound" in w and "measures the quota" in w
+    assert bench.client_bound_warning("config4", 4, 16.0, 2, 256) is None
+    assert bench.client_bound_warning("config5", 8, 16.0, 1, 256) is None          # never saturates the talker anyway
+    assert "on 2 schedulable CPUs" in bench.client_bound_warning("config2", 1, None, 1, 2)
+
+
+def test_quota_bound_replica_run_carries_the_warning(monkeypatch, capsys, port_binary, tmp_path):
+    """The same through bench.main(): a monkeypatched 3-core quota leaves one receiver thread, and the line warns."""
+    sys.path.insert(0, str(REPO))
+    import bench
+    monkeypatch.setenv("NUTS_BENCH_FULL_RECORD", str(tmp_path / "full.json"))
+    monkeypatch.setattr(bench.workloads, "cgroup_cpu_quota", lambda: 3.0)
+    monkeypatch.setattr(bench.workloads, "MAX_CLIENT_THREADS", 4)          # restored after the test: main() lowers it
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "1", "--warmup", "0", "--lines-per-step", "100", "--workload", "config2",
+                                      "--binary", "port", "--no-extras"])
+    assert bench.main() == 0
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["host"]["receiver_threads_per_replica"] == 1 and line["host"]["cgroup_cpu_quota_cores"] == 3.0
+    assert line["warnings_count"] == 1 and "under a 3-core quota leave 1 receiver thread each: client-bound" in line["warnings"][0]
+    assert line["delivered"] == line["expected_delivered"] == 900
+
+
+def test_roofline_fraction_outside_its_band_is_named_in_the_line():
+    """VERDICT r3 item 4 / ADVICE r3: below 0.85 or above 1.02 the line carries a 'roofline:' warning; the gpu tier asserts
+    that invariant rather than the band itself."""
+    sys.path.insert(0, str(REPO))
+    import bench
+    rf = {"frac": 0.95, "frac_extrapolated": 0.96, "probe": {"full_open": {"written_lines_per_s_wall_all": [1, 2, 3]}}}
+    assert bench.roofline_warnings(rf, [20.0, 0, 0]) == [] and bench.roofline_warnings(None, None) == []
+    low = bench.roofline_warnings({**rf, "frac": 0.831, "frac_extrapolated": 1.051}, [64.0, 0, 0])
+    assert len(low) == 1 and low[0].startswith("roofline:") and "0.831" in low[0] and "1.051" in low[0] and "read 64" in low[0]
+    high = bench.roofline_warnings({**rf, "frac": 1.04}, None)
+    assert len(high) == 1 and high[0].startswith("roofline:") and "cannot exceed" in high[0]
+
+
+def test_compact_line_fits_the_drivers_tail_even_with_long_warnings():
+    """Round 3's line was 12 KB and the driver's record kept its last ~8 KB: load average and the restatement leg were cut
+    off.  Built here from a committed full record of that very shape, with six 1 KB warnings on top."""
+    sys.path.insert(0, str(REPO))
+    import bench
+    full = json.loads((REPO / "profiles" / "bench_r03_driverargs_run4_final_mi355xhost.json").read_text())
+    line = bench.compact_line(full, "gpurun_out/bench_full_n1.json")
+    assert len(json.dumps(line)) <= bench.LINE_BUDGET
+    assert line["host"]["loadavg_before_run"] == full["host"]["loadavg_before_run"]
+    assert line["cpu_baseline_port"]["ratio_to_timed_run"] == full["cpu_baseline_port"]["ratio_to_timed_run"]
+    assert line["cpu_baseline_port"]["busy_all_reps"] == [d["server_busy_frac"] for d in full["cpu_baseline_port"]["diagnostics_all_reps"]]
+    noisy = {**full, "warnings": [f"config4 repetition {k}: " + "x" * 1000 for k in range(9)]}
+    line = bench.compact_line(noisy, "gpurun_out/bench_full_n1.json", tight=1)
+    assert len(json.dumps(line)) <= bench.LINE_BUDGET and line["warnings_count"] == 9 and len(line["warnings"]) == 6
+    assert line["value"] == full["value"] and line["roofline"]["frac"] == full["roofline"]["frac"]
+
+
+def test_every_worker_reports_its_counters_and_its_own_window(port_binary):
+    """a receiver thread that got no loop turn between the last delivery and the stop used to report
+    cpu_s = 0 (a fabricated 'busy 0.00'); it now samples on its way out, over the window it really covered."""
+    res = workloads.config2(lines=300, warmup=10, binary=port_binary)
+    assert res["spin"] == 1 and res["workers"]
+    for w in res["workers"]:
+        assert w["window_s"] >= res["wall_s"] * 0.5 and w["cpu_s"] > 0 and 0 < w["busy_frac"] <= 1.05, w
+
+
+def test_placement_tops_up_a_set_too_small_to_hold_the_harness(monkeypatch):
+    """a 2-core / 4-thread host.  One thread per core would leave talker + 1 receiver (client-bound) and
+    nothing for config #5's second talker; the set is topped up with the sibling threads, quietest first."""
+    from nuts333_amd import placement
+    cpus = [0, 1, 2, 3]
+    monkeypatch.setattr(placement.os, "sched_getaffinity", lambda _pid: set(cpus))
+    monkeypatch.setattr(placement, "topology", lambda allowed: ({c: 0 for c in cpus}, {0: 0, 1: 1, 2: 0, 3: 1}))
+    monkeypatch.setattr(placement, "busy_sample", lambda interval=0.25: {0: 0.0, 1: 0.0, 2: 0.5, 3: 0.0})
+    monkeypatch.delenv("NUTS_BENCH_CPUS", raising=False)
+    got = placement.choose()
+    assert got["policy"] == "quiet" and got["sets"] == [[1, 0, 3, 2]] and "topped up with 2" in got["note"]
 
 
 def test_run_reports_where_the_talkers_wall_clock_went(port_binary):

@@ -29,15 +29,62 @@ def driver_lines() -> list[tuple[str, dict, dict]]:
                     line = json.loads(cand)
                 except json.JSONDecodeError:
                     line = None
-        if line is None:            # the tail may have been cut: the driver's own parse has the contract keys at least
-            line = rec.get("parsed") or {}
+        if line is None:            # the tail was cut: the driver's own parse has the contract keys, the cut tail the rest
+            line = dict(rec.get("parsed") or {})
+            line.update(salvage(tail, line))
         out.append((f.name, rec, line))
     return out
 
 
+def salvage(tail: str, parsed: dict) -> dict:
+    """What a stdout tail that lost the head of its JSON line still holds (BENCH_r03.json: the driver keeps ~8 KB, the
+    round-3 line was 12 KB).  Whole sub-objects are decoded where they start inside the tail; nothing is guessed.  The
+    restatement leg's repetitions survive only as their diagnostics (wall clock, busy fraction): the rate of each is the
+    run's own delivery count over that wall clock, and the entry says how many of the three were visible."""
+    dec, got = json.JSONDecoder(), {}
+
+    def after(key: str, start: int = 0):
+        i = tail.find(f'"{key}": ', start)
+        if i < 0:
+            return None, -1
+        try:
+            val, end = dec.raw_decode(tail, i + len(key) + 4)
+            return val, end
+        except json.JSONDecodeError:
+            return None, -1
+
+    for key in ("configs", "warnings", "extras_errors", "device_floor"):
+        val, _ = after(key)
+        if val is not None:
+            got[key] = val
+    head = tail[:tail.find('"configs": ')] if '"configs": ' in tail else ""
+    reps, pos = [], 0
+    while True:
+        i = head.find('{"wall_s": ', pos)
+        if i < 0:
+            break
+        try:
+            d, pos = dec.raw_decode(head, i)
+            reps.append(d)
+        except json.JSONDecodeError:
+            break
+    la = re.search(r'"loadavg_before": \[([0-9.]+)', head)
+    if la:
+        got["host"] = {"loadavg_before_run": [float(la.group(1))], "salvaged": "first load average still visible in the cut tail (a restatement repetition's)"}
+    deliveries = re.search(r"(\d+) deliveries", (parsed.get("cpu_baseline") or {}).get("sample", ""))
+    if reps and deliveries and parsed.get("value"):
+        rates = [int(deliveries.group(1)) / d["wall_s"] for d in reps]
+        mid = sorted(rates)[(len(rates) - 1) // 2]          # the lower of two: nothing is rounded up in a salvaged entry
+        got["cpu_baseline_port"] = {"value": mid, "ratio_to_timed_run": mid / parsed["value"], "rate_all_reps": rates,
+                                    "server_cpu_us_per_written_line": reps[rates.index(mid)].get("server_cpu_us_per_written_line"),
+                                    "salvaged": f"{len(reps)} of 3 repetitions visible in the driver's cut stdout tail: " + " and ".join(f"{r:,.0f}" for r in rates)
+                                                + " = deliveries / wall_s of each"}
+    return got
+
+
 def record() -> str:
     """Section 0: the driver-run lines, one row per round (the number of record is the driver's)."""
-    rows = ["| Driver file | command | headline workload | **delivered lines/s** | ms/step | host load average | `roofline.frac` as printed | vs demonstrated peak | vs CPU-time extrapolation | restatement leg (`cpu_baseline_port`) | configs medians #1 input/s Â· #2 Â· #3 Â· #4 Â· #5 |",
+    rows = ["| Driver file | command | headline workload | **delivered lines/s** | ms/step | host load average | `roofline.frac` as printed | vs demonstrated peak | vs CPU-time extrapolation | restatement leg (`cpu_baseline_port`) | configs medians #1 input/s Â· #2 Â· #3 (Â· #3 with six rooms, from round 4) Â· #4 Â· #5 |",
             "|---|---|---|---|---|---|---|---|---|---|---|"]
     for name, rec, j in driver_lines():
         rf = j.get("roofline") or {}
@@ -55,8 +102,9 @@ def record() -> str:
                     f"| `{name}` (`{rec.get('head', '?')}`) | `{rec.get('cmd', '?')}` | {wl.split(',')[0]} | **{j.get('value', 0):,.0f}** | {j.get('ms_per_step', '?')} | "
                     f"{((j.get('host') or {}).get('loadavg_before_run') or ['?'])[0]} | {rf.get('frac', 'â€”')} | â€” | â€” | ")
         rows[-1] += (f"{port['value']:,.0f} (Ã—{ratio:.2f} of the timed run"
-                     + (f", {port['server_cpu_us_per_written_line']} Âµs/line" if port.get("server_cpu_us_per_written_line") else "") + ")" if port.get("value") else "â€”")
-        rows[-1] += " | " + (" Â· ".join(f"{cs[k]:,.0f}" for k in ("config1", "config2", "config3", "config4", "config5") if k in cs) or "â€”") + " |"
+                     + (f", {port['server_cpu_us_per_written_line']} Âµs/line" if port.get("server_cpu_us_per_written_line") else "")
+                     + (f"; {port['salvaged']}" if port.get("salvaged") else "") + ")" if port.get("value") else "â€”")
+        rows[-1] += " | " + (" Â· ".join(f"{cs[k]:,.0f}" for k in ("config1", "config2", "config3", "config3_six_rooms", "config4", "config5") if k in cs) or "â€”") + " |"
     if len(rows) == 2:
         return ""
     notes = []
@@ -69,8 +117,12 @@ def record() -> str:
             "same host are the spread around them. `vs demonstrated peak` = lines written per second by the talker Ã· the best wall-clock rate a\n"
             "system-call-only loop reached in the same line; `vs CPU-time extrapolation` = the same Ã· the closed loop's writes per CPU second.\n\n"
             + "\n".join(rows) + "\n" + ("\n" + "\n".join(notes) + "\n" if notes else "") +
-            "\nRound 2's restatement leg read 5.3Ã— low at equal CPU per line and the line could not say why (one repetition, no counters): see\n"
-            "`DESIGN.md` Â§10 for what the evidence allows and what round 3 records so that a repeat explains itself.\n")
+            "\nRound 2's restatement leg read 5.3Ã— low at equal CPU per line and the line could not say why (one repetition, no counters). The\n"
+            "driver's own round-3 run shows the same leg clean (talker busy 0.999â€“1.00 in every visible repetition, `warnings: []`); the cause of\n"
+            "round 2's reading stays undetermined and the item is closed (`DESIGN.md` Â§10). `BENCH_r03.json` holds only the last ~8 KB of a 12 KB\n"
+            "line, so its load average, restatement leg and configs above are read out of that cut tail (`salvage()` in the generator; nothing is\n"
+            "guessed, the entry says what was visible). From round 4 the line printed on stdout is a compact record under 6 KB that the driver's\n"
+            "tail keeps whole; the full record goes to `gpurun_out/bench_full_n<N>.json`.\n")
 
 
 def round2() -> str:
@@ -245,7 +297,7 @@ Independent replicas (one quiet L3 group each, no GPU opened by any rank): N=2 â
 
 {probe_table}
 
-### 2S.3 Looking for round 2's stalled leg (`tools/stall_hunt.py`)
+### 2S.3 Looking for round 2's stalled leg (`profiles/stall_hunt_r03_experiment.py`)
 
 Round 2's driver line had the restatement at 0.19 of the reference's rate with the same CPU per line, and no counters to explain it
 (`DESIGN.md` Â§10). The exact sequence â€” three probe legs, then the restatement on 2,000 `.shout` lines to 999 recipients â€” repeated on the
