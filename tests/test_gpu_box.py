@@ -239,10 +239,11 @@ def test_device_launch_floor_is_recorded():
     print("\n[device floor]", json.dumps(floor))
 
 
-def test_replicas_never_open_a_gpu():
+def test_replicas_never_open_a_gpu(tmp_path):
     """"no GPU is touched by any replica", literally.  libdrm announces every amdgpu device a process
     opens on this box with a complaint about a missing amdgpu.ids file; two replicas must run without one."""
     p = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--lines-per-step", "20"],
+                       env={**os.environ, "NUTS_BENCH_FULL_RECORD": str(tmp_path / "full.json")},
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-800:]
     j = json.loads(p.stdout.decode().strip().splitlines()[-1])
