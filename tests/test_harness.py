@@ -573,7 +573,8 @@ def test_quota_bound_replica_run_carries_the_warning(monkeypatch, capsys, port_b
     assert bench.main() == 0
     line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert line["host"]["receiver_threads_per_replica"] == 1 and line["host"]["cgroup_cpu_quota_cores"] == 3.0
-    assert line["warnings_count"] == 1 and "under a 3-core quota leave 1 receiver thread each: client-bound" in line["warnings"][0]
+    # (first in the list; a 100-line run with one receiver may ALSO be reported as a harness stall, which is the point)
+    assert line["warnings_count"] >= 1 and "under a 3-core quota leave 1 receiver thread each: client-bound" in line["warnings"][0]
     assert line["delivered"] == line["expected_delivered"] == 900
 
 
