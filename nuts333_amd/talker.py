@@ -32,6 +32,9 @@ PORT_BINARY = REPO / "oracle" / "_build" / "talker_port"
 _BOOT_RE = re.compile(r"Booted successfully with PID (\d+)")
 
 
+_HANDED_OUT: set[int] = set()
+
+
 def free_ports(n: int = 3) -> list[int]:
     """n distinct currently-free loopback TCP ports.  Under a multi-rank launch (RANK set) each rank
     draws from its own 400-port window, so replicas booted at the same instant cannot pick the same
@@ -51,17 +54,33 @@ def free_ports(n: int = 3) -> list[int]:
             ports.append(p)
             if len(ports) == n:
                 return ports
-    socks, ports = [], []
+    # Not bind(port 0): that hands out EPHEMERAL ports, the range every client connection of the suite draws its source
+    # port from -- between our probe and the talker's bind() a scripted client or one of a load generator's 1000 sockets can
+    # be given the very port (seen once in ~200 boots as "Can't bind to main port: Address already in use"; the talker sets
+    # SO_REUSEADDR, nuts333.c:1183, but an auto-bound client socket does not).  Draw from a window below the ephemeral range.
+    lo, hi = 12000, 20000
     try:
-        for _ in range(n):
-            s = socket.socket()
-            s.bind(("127.0.0.1", 0))
-            socks.append(s)
-            ports.append(s.getsockname()[1])
-    finally:
-        for s in socks:
-            s.close()
-    return ports
+        hi = min(hi, int(Path("/proc/sys/net/ipv4/ip_local_port_range").read_text().split()[0]))
+    except (OSError, ValueError, IndexError):
+        pass
+    ports = []
+    start = int.from_bytes(os.urandom(4), "little") % (hi - lo)
+    for k in range(hi - lo):
+        p = lo + (start + k) % (hi - lo)
+        if p in _HANDED_OUT:          # promised to an earlier caller of this process that may not have bound it yet
+            continue
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", p))
+            except OSError:
+                continue
+        ports.append(p)
+        if len(ports) == n:
+            if len(_HANDED_OUT) > 2000:
+                _HANDED_OUT.clear()
+            _HANDED_OUT.update(ports)
+            return ports
+    raise RuntimeError(f"no {n} free TCP ports in {lo}-{hi}")
 
 
 class Talker:

@@ -58,6 +58,14 @@ def test_config_render_fits_the_parser_limits():
     assert "lg lounge co BOTH ACCEPT" in text and "dr drive ha PUB" in text
 
 
+def test_talker_ports_come_from_below_the_ephemeral_range():
+    """A talker's three ports must not be ports the kernel may hand to a client connection as its source port between our
+    probe and the talker's bind() (round 4: one "Can't bind to main port: Address already in use" in the suite)."""
+    low = int(Path("/proc/sys/net/ipv4/ip_local_port_range").read_text().split()[0])
+    got = [p for _ in range(50) for p in free_ports(3)]
+    assert len(set(got)) == 150 and all(1024 < p < low for p in got)
+
+
 def test_both_talkers_accept_the_generated_tree(tmp_path, port_binary):
     bins = [port_binary]
     from nuts333_amd.talker import REF_BINARY
