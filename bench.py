@@ -188,10 +188,32 @@ def all_configs(binary: Path, pin: bool, headline_name: str, headline: dict, att
                 why = workloads.attribute_stall(r, saturating=name in SATURATING)
                 if why:
                     warnings.append(f"{name} repetition {k + 1}: {why}")
+        slow = slow_core_warning(name, runs)
+        if slow:
+            warnings.append(slow)
         out.append(e)
         print(f"[bench] {name}: {e['delivered_lines_per_s']:,.0f} delivered/s, {e['input_lines_per_s']:,.0f} input/s, "
               f"exact={e['exact']} ({time.time() - t:.1f}s)", file=sys.stderr, flush=True)
     return out
+
+
+#: repetitions of one saturating configuration further apart than this (max / min rate) are named in `warnings`
+SPREAD_LIMIT = 1.15
+
+
+def slow_core_warning(name: str, runs: list[dict]) -> str | None:
+    """Repetitions of a saturating configuration that differ by more than SPREAD_LIMIT although the talker was the
+    bottleneck in each (busy >= 0.9: no stall to attribute) ran on a core that was itself slower for a while -- another
+    tenant on the sibling thread or in the L3: it shows in the CPU cost of a line, which is quoted."""
+    if name not in SATURATING or len(runs) < 2:
+        return None
+    rates = [r["delivered_lines_per_s"] for r in runs]
+    if min(rates) <= 0 or max(rates) / min(rates) <= SPREAD_LIMIT or any(r["servers"][0]["busy_frac"] < 0.9 for r in runs):
+        return None
+    cost = [r["servers"][0]["cpu_us_per_written_line"] for r in runs]
+    return (f"{name}: repetitions {' / '.join(f'{x:,.0f}' for x in rates)} lines/s spread x{max(rates) / min(rates):.2f} with the talker "
+            f">= {min(r['servers'][0]['busy_frac'] for r in runs):.2f} busy in each: the core was slower, not the harness "
+            f"(server CPU per written line {' / '.join(f'{c:.2f}' for c in cost)} us; shared host)")
 
 
 #: what a reader of the line alone must know about the two readings of BASELINE.json's configuration #3

@@ -586,6 +586,21 @@ def test_quota_bound_replica_run_carries_the_warning(monkeypatch, capsys, port_b
     assert line["delivered"] == line["expected_delivered"] == 900
 
 
+def test_repetitions_far_apart_on_a_busy_talker_are_named_as_a_slow_core():
+    """Round 4's confirmation run on the box (load average 39): config #4 read 623 k / 466 k / 538 k lines/s with the talker 1.00 busy
+    every time and `warnings: []`.  Nothing stalled -- the core was slower (1.85 us per line against 1.31) -- and the line now says so."""
+    sys.path.insert(0, str(REPO))
+    import bench
+
+    def run(rate, busy, cost):
+        return {"delivered_lines_per_s": rate, "servers": [{"busy_frac": busy, "cpu_us_per_written_line": cost}]}
+    w = bench.slow_core_warning("config4", [run(622932.9, 1.0, 1.60), run(466427.7, 0.996, 2.14), run(537852.9, 0.997, 1.85)])
+    assert w.startswith("config4: repetitions 622,933 / 466,428 / 537,853") and "x1.34" in w and "1.60 / 2.14 / 1.85 us" in w
+    assert bench.slow_core_warning("config4", [run(750e3, 1.0, 1.3), run(760e3, 1.0, 1.3), run(740e3, 1.0, 1.3)]) is None
+    assert bench.slow_core_warning("config4", [run(750e3, 1.0, 1.3), run(400e3, 0.5, 1.3)]) is None      # a stall: attribute_stall's business
+    assert bench.slow_core_warning("config1", [run(200e3, 0.6, 3.0), run(150e3, 0.6, 3.0)]) is None      # never saturates the talker
+
+
 def test_roofline_fraction_outside_its_band_is_named_in_the_line():
     """VERDICT r3 item 4 / ADVICE r3: below 0.85 or above 1.02 the line carries a 'roofline:' warning; the gpu tier asserts
     that invariant rather than the band itself."""
