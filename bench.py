@@ -34,7 +34,8 @@ Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE 
   * ``cpu_baseline`` is the same run by construction (the CPU path is the only path);
     ``cpu_baseline_port`` is the independent second number: our restatement on the same workload and size,
     three repetitions, median, each with the counters that explain its wall clock (``workloads.leg_diagnostics``).
-  * ``warnings``: every leg whose talker was not the bottleneck although the configuration saturates it, with the
+  * ``warnings`` (full record: every one; the line: ``compact_warnings`` -- at most 6, one of each kind first, each cut to
+    400 characters, ``warnings_count`` beside them): every leg whose talker was not the bottleneck although the configuration saturates it, with the
     stall attributed from the leg's own counters (talker runnable but off its core / sender's receiver thread
     descheduled / cgroup throttle), and a restatement/reference ratio outside [0.9, 1.1].
   * exit code: 0 only when the timed run was exact AND every configuration in ``configs`` was.
@@ -42,6 +43,9 @@ Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE 
     ~8 KB of stdout in ``BENCH_rNN.json`` and round 3's 12 KB line lost its head there (load average, restatement leg).  The
     FULL record -- every probe repetition, every repetition's counters -- goes to ``gpurun_out/bench_full_n<N>.json``
     (``full_record`` in the line names it; ``NUTS_BENCH_FULL_RECORD`` overrides the path, ``--full-line`` prints it instead).
+    That file comes back from builder-run gpurun calls only; the driver's round-end run does not pull it, so the line
+    carries what explains it: per probe leg the rates, CPU/wall ratio and load average (``roofline.probe_legs``).
+  * ``cpu_baseline_O0``: the headline workload on oracle/_ref/nuts333_O0 (the reference's as-shipped flags: no -O), x 3.
 """
 from __future__ import annotations
 
@@ -59,7 +63,7 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 from nuts333_amd import placement, workloads  # noqa: E402
-from nuts333_amd.talker import PORT_BINARY  # noqa: E402
+from nuts333_amd.talker import PORT_BINARY, REF_BINARY_O0  # noqa: E402
 
 METRIC = "delivered_broadcast_lines_per_s"
 UNIT = "lines/s"
@@ -216,6 +220,30 @@ def slow_core_warning(name: str, runs: list[dict]) -> str | None:
             f"(server CPU per written line {' / '.join(f'{c:.2f}' for c in cost)} us; shared host)")
 
 
+def as_shipped_flags_leg(workload: str, total: int, warm: int, pin: bool, timed: dict, attempt, warnings: list[str]) -> dict | None:
+    """the reference's own ``build`` script compiles WITHOUT an -O flag (/root/reference/build:7,15); the
+    headline binary oracle/_ref/nuts333 is -O2 (oracle/Makefile).  This leg runs the headline workload, same size, three
+    times on oracle/_ref/nuts333_O0 -- the same sources, gcc's default -O0 -- so the driver's record also holds what the
+    maintainers' flags give (round 1 on the box: about 4 % below the -O2 figure)."""
+    reps = [r for r in (attempt(f"as-shipped-flags (-O0) build on the headline workload, repetition {k + 1}",
+                                lambda: measured(lambda: run_workload(workload, total, warm, REF_BINARY_O0, pin))) for k in range(3))
+            if r is not None]
+    if not reps:
+        return None
+    p, _ = sorted(reps, key=lambda pc: pc[0]["delivered_lines_per_s"])[len(reps) // 2]
+    for k, (r, c) in enumerate(reps):
+        leg_report(f"{workload}: -O0 build repetition {k + 1}", r, c, warnings)
+    ratio = p["delivered_lines_per_s"] / timed["delivered_lines_per_s"] if timed["delivered_lines_per_s"] else None
+    return {"value": round(p["delivered_lines_per_s"], 1), "unit": UNIT, "cores": 1, "kind": "reference",
+            "binary": str(REF_BINARY_O0.relative_to(REPO)), "flags": "gcc, no -O flag (as /root/reference/build:7,15 ships it)",
+            "sample": f"same workload and size as the timed run: {p['input_lines']} input lines, {p['deliveries']} deliveries; median of {len(reps)}",
+            "reps": len(reps), "exact": all(r["exact"] for r, _ in reps),
+            "rate_all_reps": [round(r["delivered_lines_per_s"], 1) for r, _ in reps],
+            "ratio_to_timed_run": round(ratio, 3) if ratio else None,
+            "server_cpu_us_per_written_line": round(p["servers"][0]["cpu_us_per_written_line"], 3),
+            "busy_all_reps": [round(r["servers"][0]["busy_frac"], 3) for r, _ in reps]}
+
+
 #: what a reader of the line alone must know about the two readings of BASELINE.json's configuration #3
 CONFIG_NOTES = {
     "config3": "the reference's shipped datafiles/config:34-39 defines 5 rooms, not BASELINE.json's 6: this entry is the shipped "
@@ -223,6 +251,10 @@ CONFIG_NOTES = {
     "config3_six_rooms": "BASELINE.json configs[2] literally ('all 6 rooms'): the shipped 5 + a generated sixth room 'shop'; "
                          "same 100 clients, 200 lines each, seed 333",
 }
+
+#: the same two notes as the compact line words them
+COMPACT_NOTES = {"config3": "shipped datafiles/config:34-39 has 5 rooms, not BASELINE.json's 6: these are the shipped 5",
+                 "config3_six_rooms": "BASELINE.json's 'all 6 rooms' literally: the shipped 5 + a generated sixth, 'shop'"}
 
 PROBE_REPS = 3
 PROBE_TIMEOUT_S = 120
@@ -252,6 +284,10 @@ def syscall_roofline(res: dict, achieved: float) -> dict:
         med = sorted(runs, key=lambda r: r["written_lines_per_s_wall"])[len(runs) // 2]
         return {**med, "written_lines_per_s_wall_all": [r["written_lines_per_s_wall"] for r in runs],
                 "written_lines_per_s_cpu_all": [r["written_lines_per_s_cpu"] for r in runs],
+                # CPU time of the probing thread / wall time, per repetition: < 1 = the thread waited or was off its core,
+                # ~1 at a low rate = the core itself was slower
+                "cpu_over_wall_all": [round(r["cpu_ns_per_line"] / r["wall_ns_per_line"], 3) if r.get("wall_ns_per_line") else None for r in runs],
+                "loadavg_before_all": [(c["loadavg_before"] or [None])[0] for c in ctxs],
                 "bytes_ok": all(r["bytes_ok"] for r in runs), "reps": len(runs),
                 "cgroup_throttled_periods": sum(c["cgroup_throttled_periods"] or 0 for c in ctxs),
                 "loadavg_before": ctxs[0]["loadavg_before"]}
@@ -281,6 +317,58 @@ def syscall_roofline(res: dict, achieved: float) -> dict:
                     "peak_extrapolated = 1e9 x writes / CPU ns of the closed loop (median of 3), what round 2 quoted"}
 
 
+def probe_leg_summary(leg: dict) -> dict:
+    """What the compact line keeps of one probe leg: every repetition's wall-clock rate, the MEDIAN repetition's CPU/wall
+    ratio of the probing thread and the load average before the leg -- enough to tell, from the line alone, a probing
+    thread that waited from a core that ran slowly (BENCH_r04's open loop read 0.69 x the closed one
+    and the record could not say why)."""
+    walls = leg["written_lines_per_s_wall_all"]
+    ratios = leg.get("cpu_over_wall_all") or []
+    med = sorted(range(len(walls)), key=lambda i: walls[i])[len(walls) // 2]
+    la = leg.get("loadavg_before")
+    return {"wall_all": walls, "cpu_over_wall": ratios[med] if med < len(ratios) else None,
+            "loadavg_before": la[0] if isinstance(la, list) and la else la}
+
+
+#: an open loop below this fraction of the closed loop contradicts its own definition (the talker thread never waits)
+PROBE_OPEN_FLOOR = 0.9
+#: below this CPU/wall ratio the probing thread spent the difference waiting or descheduled, not computing
+PROBE_BUSY_FLOOR = 0.9
+
+
+def _probe_reading(leg: dict) -> str:
+    """Which of the two readings a slow probe leg was, from its median repetition's CPU time / wall time."""
+    r = probe_leg_summary(leg)["cpu_over_wall"]
+    if r is None:
+        return "CPU/wall of the probing thread not recorded"
+    if r < PROBE_BUSY_FLOOR:
+        return (f"the probing thread was on its core only {r:.2f} of the wall clock: it waited (blocked in write(2) on a full "
+                f"socket, or select() slept) or was descheduled")
+    return f"the probing thread was busy {r:.2f} of the wall clock: the core itself ran slower (sibling thread or L3 shared with another tenant)"
+
+
+def probe_warnings(roofline: dict | None) -> list[str]:
+    """The probe legs explain themselves: an open loop slower than 0.9 x the closed loop, or a full
+    leg whose repetitions spread more than SPREAD_LIMIT, is named together with the reading that says which it was.
+    Mirrors slow_core_warning; looks only at figures the probe already printed."""
+    if not roofline or "probe" not in roofline:
+        return []
+    legs = {"open-loop": roofline["probe"]["full_open"], "closed-loop": roofline["probe"]["full_closed"]}
+    out = []
+    o = statistics.median(legs["open-loop"]["written_lines_per_s_wall_all"])
+    c = statistics.median(legs["closed-loop"]["written_lines_per_s_wall_all"])
+    if c > 0 and o < PROBE_OPEN_FLOOR * c:
+        out.append(f"probe: open-loop leg median {o:,.0f} lines/s is {o / c:.2f} x the closed-loop median {c:,.0f} although its talker "
+                   f"thread never has to wait: {_probe_reading(legs['open-loop'])}")
+    for name, leg in legs.items():
+        w = leg["written_lines_per_s_wall_all"]
+        if len(w) >= 2 and min(w) > 0 and max(w) / min(w) > SPREAD_LIMIT:
+            out.append(f"probe: {name} leg repetitions {' / '.join(f'{x:,.0f}' for x in w)} lines/s spread x{max(w) / min(w):.2f} "
+                       f"(CPU/wall per repetition {leg.get('cpu_over_wall_all')}): {_probe_reading(leg)}; "
+                       f"`peak` is the max over repetitions and is good to about +-0.03")
+    return out
+
+
 #: the driver's record keeps about the last 8 KB of stdout (stderr tail included): the line must fit with room to spare
 LINE_BUDGET = 6000
 
@@ -289,12 +377,54 @@ def _short(text: str, n: int) -> str:
     return text if len(text) <= n else text[:n - 3] + "..."
 
 
+#: how many warnings / extras errors the line keeps, and how long each may be (normal, tight)
+WARNINGS_KEPT, WARNING_LEN, ERRORS_KEPT, ERROR_LEN = 6, (400, 160), 6, 300
+
+
+def _warning_kind(w: str) -> str:
+    """One word per kind of warning bench.py emits, so that the line's few slots go to different kinds first."""
+    if w.startswith("roofline:"):
+        return "roofline"
+    if w.startswith("probe:"):
+        return "probe"
+    if w.startswith("restatement/reference"):
+        return "ratio"
+    if "client-bound" in w:
+        return "client-bound"
+    if "the core was slower" in w:
+        return "slow-core"
+    if "harness stall" in w:
+        return "stall"
+    return "other"
+
+
+def compact_warnings(warnings: list[str], tight: int = 0) -> list[str]:
+    """What the line promises of ``warnings``: at most WARNINGS_KEPT of them, the first of EACH KIND before any
+    second one of a kind (a noisy configuration adds one stall warning per repetition and would otherwise crowd out the
+    roofline / ratio / client-bound ones), in their original order, each cut to WARNING_LEN characters.  ``warnings_count``
+    beside it is the number there were; the full record holds every one whole."""
+    first, seen = [], set()
+    for i, w in enumerate(warnings):
+        k = _warning_kind(w)
+        if k not in seen:
+            seen.add(k)
+            first.append(i)
+    rest = [i for i in range(len(warnings)) if i not in set(first)]
+    keep = sorted((first + rest)[:WARNINGS_KEPT])
+    return [_short(warnings[i], WARNING_LEN[1 if tight else 0]) for i in keep]
+
+
+def compact_errors(errors: list[str]) -> list[str]:
+    return [_short(e, ERROR_LEN) for e in errors[:ERRORS_KEPT]]
+
+
 def compact_line(full: dict, full_record: str | None, *, tight: int = 0) -> dict:
     """The record that goes to stdout: every contract key, every headline figure, every configuration's rate and
-    exactness, every warning -- and none of the per-repetition counters (those are in the full record).  Nothing here
-    is recomputed: each value is copied from ``full``.  ``tight`` > 0 (a line still over LINE_BUDGET, i.e. many long warnings) shortens
-    the free-text fields further, never the figures."""
-    wlen, notes = (400, True) if tight == 0 else (160, False)
+    exactness, the warnings as ``compact_warnings`` keeps them (count beside them) -- and none of the per-repetition
+    counters (those are in the full record).  Nothing here is recomputed: each value is copied from ``full``.
+    ``tight`` > 0 (a line still over LINE_BUDGET, i.e. many long warnings) shortens the free-text fields further, never
+    the figures."""
+    notes = tight == 0
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "gpu_used", "classification", "delivered", "expected_delivered", "input_lines_per_s",
             "ack_latency_us", "server_cpu_us_per_written_line", "server_busy_frac", "server_syscalls", "configs_all_exact")
@@ -313,34 +443,41 @@ def compact_line(full: dict, full_record: str | None, *, tight: int = 0) -> dict
                                                     "server_cpu_us_per_written_line", "cpu_per_line_ratio_to_timed_run")}
         c["cpu_baseline_port"]["busy_all_reps"] = [x["server_busy_frac"] for x in p["diagnostics_all_reps"]]
         c["cpu_baseline_port"]["loadavg_all_reps"] = [(x.get("loadavg_before") or [None])[0] for x in p["diagnostics_all_reps"]]
+    o0 = full.get("cpu_baseline_O0")
+    if o0:
+        c["cpu_baseline_O0"] = {k: o0[k] for k in ("value", "kind", "flags", "reps", "exact", "rate_all_reps", "ratio_to_timed_run",
+                                                   "server_cpu_us_per_written_line")}
+        c["cpu_baseline_O0"]["flags"] = "no -O flag (reference/build:7,15)"
     if "configs" in full:
         c["configs"] = []
         for e in full["configs"]:
             ce = {k: e[k] for k in ("name", "n", "delivered_lines_per_s", "input_lines_per_s", "delivered", "expected_delivered", "exact",
-                                    "reps", "rate_all_reps", "server_busy_frac", "includes_headline_run", "error") if k in e}
+                                    "reps", "rate_all_reps", "server_busy_frac", "error") if k in e}
+            if e.get("includes_headline_run"):          # (absent = false: three fresh repetitions)
+                ce["includes_headline_run"] = True
             if "workload" in e:
-                ce["workload"] = _short(e["workload"].split(": ", 1)[-1], 90)
+                ce["workload"] = _short(e["workload"].split(": ", 1)[-1], 80)
             if "netlink" in e:
                 ce["netlink"] = {k: e["netlink"][k] for k in ("writes_t1_to_t2", "writes_t2_to_t1", "exact") if k in e["netlink"]}
             if "note" in e and notes:
-                ce["note"] = _short(e["note"], 130)
+                ce["note"] = COMPACT_NOTES.get(e.get("name"), _short(e["note"], 80))
             c["configs"].append(ce)
     f = full.get("device_floor")
     if "device_floor" in full:
         c["device_floor"] = {k: f[k] for k in ("kernel_launch_plus_sync_us", "graph_replay_plus_sync_us", "h2d_64B_kernel_d2h_69KB_sync_us")
                              if k in f} if f else None
     if "extras_errors" in full:
-        c["extras_errors"] = [_short(e, 300) for e in full["extras_errors"][:6]]
+        c["extras_errors"] = compact_errors(full["extras_errors"])
         c["extras_errors_count"] = len(full["extras_errors"])
-    c["warnings"] = [_short(w, wlen) for w in full["warnings"][:6]]
+    c["warnings"] = compact_warnings(full["warnings"], tight)
     c["warnings_count"] = len(full["warnings"])
     c["full_record"] = full_record
     r = full.get("roofline")
     if r:
         c["roofline"] = {k: v for k, v in r.items() if k not in ("probe", "note", "unit")}
         c["roofline"]["unit"] = "lines written/s on one core"
-        c["roofline"]["demonstrated_wall_all"] = {"open": r["probe"]["full_open"]["written_lines_per_s_wall_all"],
-                                                  "closed": r["probe"]["full_closed"]["written_lines_per_s_wall_all"]}
+        c["roofline"]["probe_legs"] = {"open": probe_leg_summary(r["probe"]["full_open"]),
+                                       "closed": probe_leg_summary(r["probe"]["full_closed"])}
         c["roofline"]["note"] = "host system-call ceiling; no HBM/MFMA roofline applies: no device kernel exists"
     else:
         c["roofline"] = None
@@ -348,8 +485,21 @@ def compact_line(full: dict, full_record: str | None, *, tight: int = 0) -> dict
     return c
 
 
+def render_line(full: dict, full_record: str | None) -> str:
+    """The stdout line: the compact record, in ``tight`` form when the normal one would exceed LINE_BUDGET."""
+    line = json.dumps(compact_line(full, full_record))
+    if len(line) > LINE_BUDGET:
+        line = json.dumps(compact_line(full, full_record, tight=1))
+    if len(line) > LINE_BUDGET:
+        print(f"[bench] WARNING: the line is {len(line)} bytes, over the {LINE_BUDGET}-byte budget the driver's tail keeps", file=sys.stderr, flush=True)
+    return line
+
+
 def write_full_record(full: dict, world: int) -> str | None:
-    """gpurun_out/ travels back from the GPU box (and the driver pulls it): the full record survives there."""
+    """gpurun_out/ travels back from the GPU box in the BUILDER's gpurun calls, so the full record survives those.  The
+    driver's own round-end bench run pulls only its stdout/stderr/wall files (BENCH_r04.json ``pulled_files``: n1.out,
+    n1.err, n1.wall, smi.*), not this file: whatever the driver's record must explain has to be in the compact line
+    itself."""
     path = Path(os.environ.get("NUTS_BENCH_FULL_RECORD") or REPO / "gpurun_out" / f"bench_full_n{world}.json")
     try:
         path.parent.mkdir(parents=True, exist_ok=True)
@@ -642,6 +792,7 @@ def main() -> int:
 
         roofline = attempt("syscall roofline probe", lambda: syscall_roofline(res, written_all / wall_max))
         warnings += roofline_warnings(roofline, loadavg0)
+        warnings += probe_warnings(roofline)
         if kind == "reference" and PORT_BINARY.exists():
             # the independent second number: three repetitions, median, each one able to explain its own wall clock
             reps = []
@@ -672,6 +823,10 @@ def main() -> int:
                                     f"restatement/reference delivered-rate ratio {ratio:.2f} outside [0.9, 1.1] AND CPU per line differs "
                                     f"({cpu_line:.3f} vs {srv['cpu_us_per_written_line']:.3f} us): not a harness stall -- the host moved between the legs "
                                     f"(compare rate_all_reps and configs[].rate_all_reps) or the implementations cost differently")
+        if kind == "reference" and REF_BINARY_O0.exists():
+            o0 = as_shipped_flags_leg(args.workload, total, warm, pin, res, attempt, warnings)
+            if o0:
+                out["cpu_baseline_O0"] = o0
         out["configs"] = all_configs(binary, pin, args.workload, res, attempt, headline_size=(total, warm), warnings=warnings)
         out["configs_all_exact"] = all(e.get("exact", False) for e in out["configs"])
         out["device_floor"] = attempt("device floor", device_floor_in_child)
@@ -682,13 +837,7 @@ def main() -> int:
     if args.full_line:
         print(json.dumps(out))
     else:
-        record = write_full_record(out, world)
-        line = json.dumps(compact_line(out, record))
-        if len(line) > LINE_BUDGET:
-            line = json.dumps(compact_line(out, record, tight=1))
-        if len(line) > LINE_BUDGET:
-            print(f"[bench] WARNING: the line is {len(line)} bytes, over the {LINE_BUDGET}-byte budget the driver's tail keeps", file=sys.stderr, flush=True)
-        print(line)
+        print(render_line(out, write_full_record(out, world)))
     if dist is not None:
         dist.destroy_process_group()
     for w in warnings:

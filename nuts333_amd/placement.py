@@ -117,7 +117,11 @@ def choose(n_wanted: int = 8, *, groups: int = 1, interval: float = 0.5) -> dict
     need = min(per, NEED_CPUS)
     topped = 0
     for s in sets:
-        spare = sorted((c for c in allowed if c not in used), key=lambda c: (l3[c] != l3[s[0]], round(busy.get(c, 0.0), 2), c))
+        # ... but the TALKER's own sibling thread (s[0] is the talker's CPU) goes last of all: a busy-polling receiver on
+        # it would cost the talker almost as much as a busy core (see above), so it is handed out only when nothing else
+        # is left -- by then to the last receiver or to config #5's second talker
+        spare = sorted((c for c in allowed if c not in used),
+                       key=lambda c: (core[c] == core[s[0]], l3[c] != l3[s[0]], round(busy.get(c, 0.0), 2), c))
         while len(s) < need and spare:
             c = spare.pop(0)
             s.append(c)

@@ -58,11 +58,7 @@ def free_ports(n: int = 3) -> list[int]:
     # port from -- between our probe and the talker's bind() a scripted client or one of a load generator's 1000 sockets can
     # be given the very port (seen once in ~200 boots as "Can't bind to main port: Address already in use"; the talker sets
     # SO_REUSEADDR, nuts333.c:1183, but an auto-bound client socket does not).  Draw from a window below the ephemeral range.
-    lo, hi = 12000, 20000
-    try:
-        hi = min(hi, int(Path("/proc/sys/net/ipv4/ip_local_port_range").read_text().split()[0]))
-    except (OSError, ValueError, IndexError):
-        pass
+    lo, hi = port_window()
     ports = []
     start = int.from_bytes(os.urandom(4), "little") % (hi - lo)
     for k in range(hi - lo):
@@ -81,6 +77,56 @@ def free_ports(n: int = 3) -> list[int]:
             _HANDED_OUT.update(ports)
             return ports
     raise RuntimeError(f"no {n} free TCP ports in {lo}-{hi}")
+
+
+def port_window(ephemeral: tuple[int, int] | None = None) -> tuple[int, int]:
+    """[lo, hi) to draw talker ports from: outside the kernel's ephemeral range ``ip_local_port_range`` (``ephemeral``
+    overrides the /proc reading, for the unit test).  Normally 12000 up to the range's low end (at most 20000); on a host
+    whose range starts at or below ~13000 (a common tuning is ``1024 65535``) the window below it is too small or empty
+    (a modulus by a non-positive span), so take the room above its top end, and if the range covers
+    everything, 12000-20000 inside it: a collision with a client's source port is then possible again, as it was with
+    bind(0), but nothing divides by zero and _HANDED_OUT still keeps this process's own draws apart."""
+    if ephemeral is None:
+        try:
+            a, b = Path("/proc/sys/net/ipv4/ip_local_port_range").read_text().split()[:2]
+            ephemeral = (int(a), int(b))
+        except (OSError, ValueError):
+            ephemeral = (32768, 60999)
+    e_lo, e_hi = ephemeral
+    lo, hi = 12000, min(20000, e_lo)
+    if hi - lo >= 1000:
+        return lo, hi
+    if 65535 - e_hi >= 1000:
+        return e_hi + 1, min(65536, e_hi + 1 + 8000)
+    return 12000, 20000
+
+
+def ref_marker() -> Path:
+    """Written by ``__graft_entry__.build()`` when it compiled oracle/_ref/ (so: in the container, where /root/reference
+    exists); travels to the GPU box beside the binaries (both git-ignored, neither gpurun-ignored).  Holds the sha256 of
+    each reference binary built.  Kept outside oracle/_ref/ so that a snapshot that lost that directory still says so."""
+    return REPO / "oracle" / "_build" / "ref_built.json"
+
+
+def reference_expected_but_missing() -> str | None:
+    """the marker says a reference build was made for this snapshot; if a binary it names is absent
+    or differs, say so -- callers FAIL on it instead of skipping (tests) or headlining the restatement (bench.py)."""
+    import hashlib
+    import json
+    m = ref_marker()
+    if not m.exists():
+        return None
+    try:
+        want = json.loads(m.read_text())["sha256"]
+    except (OSError, ValueError, KeyError) as e:
+        return f"{m} unreadable: {e!r}"
+    for name, digest in want.items():
+        b = REPO / "oracle" / "_ref" / name
+        if not b.exists():
+            return f"oracle/_build/ref_built.json says oracle/_ref/{name} was built for this snapshot, but it is missing"
+        if hashlib.sha256(b.read_bytes()).hexdigest() != digest:
+            return f"oracle/_ref/{name} differs from the build recorded in oracle/_build/ref_built.json"
+    return None
 
 
 class Talker:

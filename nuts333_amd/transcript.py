@@ -214,7 +214,17 @@ class Session:
         self.steps[-1]["recv"][key] = self.steps[-1]["recv"].get(key, "") + got
 
     # -- plumbing ----------------------------------------------------------------------
+    #: the talker's own replies to a toggle of ignall (toggle_ignall, nuts333.c:4463-4476)
+    _IGNALL_ON, _IGNALL_OFF = b"You are now ignoring everyone.", b"You will now hear everyone again."
+
     def _record(self, what: dict, recv: dict[str, bytes]) -> None:
+        # hears_broadcasts follows what the TALKER said, not what was typed: an abbreviated command toggles too,
+        # a level-gated refusal does not; the later of the two replies in a capture wins.  Only close()'s wait reads the flag.
+        for k, v in recv.items():
+            c = self.clients.get(k)
+            on, off = v.rfind(self._IGNALL_ON), v.rfind(self._IGNALL_OFF)
+            if c is not None and max(on, off) >= 0:
+                c.hears_broadcasts = off > on
         self.steps.append({**what, "recv": {k: normalise(v).decode("latin-1") for k, v in recv.items() if v}})
 
     def _sync(self, c: Client) -> bytes:
@@ -343,8 +353,6 @@ class Session:
         the given suffix instead."""
         c = self.clients[key]
         c.send_raw(text.encode("latin-1") + b"\n")
-        if text.strip() == ".ignall" and c.logged_in:          # a toggle (nuts333.c:5655-5667); only close()'s wait reads it
-            c.hears_broadcasts = not c.hears_broadcasts
         if flags:
             self.set_flags(key, **flags)
         if expect is not None:
@@ -464,7 +472,7 @@ class Session:
         # (single-threaded).  Wait PASSIVELY for the first byte of it on any other client -- no round trips yet, so
         # that the talker's own sequence of write(2) calls is a function of the script alone (the write-order parity
         # test relies on that) -- then one round of syncs collects it everywhere.  Nobody listening (a half-open login
-        # closed, everyone ignoring): the wait times out and the round of syncs records the silence.
+        # closed, everyone ignoring): the short wait (0.5 s, passive) runs out and the round of syncs records the silence.
         # Only listeners the broadcast can reach are waited on: logged in (a half-open login dropped by the talker
         # reads EOF for ever) and not ignoring everything (write_room skips ignall users, nuts333.c:1413; the editor sets the
         # same skip but no script closes a peer while another is in it).  Listeners on the OTHER talker of a linked pair stay
@@ -478,6 +486,8 @@ class Session:
         expect_broadcast = bool(listeners) and c.logged_in
         deadline = time.monotonic() + (5.0 if expect_broadcast else 0.5)
         seen = False
+        if not listeners and others:          # nobody who could be sent the broadcast: the short wait, passive, nothing to look for
+            time.sleep(max(0.0, deadline - time.monotonic()))
         while listeners and not seen and time.monotonic() < deadline:
             ready, _, _ = select.select(listeners, [], [], max(0.0, deadline - time.monotonic()))
             if not expect_broadcast:

@@ -29,7 +29,7 @@ from typing import Callable, Sequence
 
 from . import placement
 from . import provision as pv
-from .talker import PORT_BINARY, REF_BINARY, Talker, free_ports
+from .talker import PORT_BINARY, REF_BINARY, Talker, free_ports, reference_expected_but_missing
 
 HERE = Path(__file__).resolve().parent
 LOADGEN_SRC = HERE / "loadgen" / "loadgen.c"
@@ -96,6 +96,10 @@ def pick_binary(kind: str = "auto") -> tuple[Path, str]:
             raise FileNotFoundError("oracle/_build/talker_port is not built")
         return PORT_BINARY, "port_fast"
     os.environ.pop("NUTS_PORT_FAST", None)
+    if kind in ("reference", "auto"):
+        lost = reference_expected_but_missing()
+        if lost:          # never fall back to the restatement in silence when the reference was built for this snapshot
+            raise FileNotFoundError(lost)
     if kind in ("reference", "auto") and REF_BINARY.exists():
         return REF_BINARY, "reference"
     if kind == "reference":

@@ -21,7 +21,7 @@ from pathlib import Path
 import pytest
 
 from nuts333_amd import workloads
-from nuts333_amd.talker import PORT_BINARY, REF_BINARY
+from nuts333_amd.talker import PORT_BINARY, REF_BINARY, REF_BINARY_O0, reference_expected_but_missing
 
 pytestmark = pytest.mark.gpu
 REPO = Path(__file__).resolve().parent.parent
@@ -31,6 +31,9 @@ def _binary(impl: str) -> Path:
     if impl == "port":
         assert PORT_BINARY.exists()
         return PORT_BINARY
+    lost = reference_expected_but_missing()
+    if lost:          # built for this snapshot and gone: red, not "N passed, M skipped" 
+        pytest.fail(lost)
     if not REF_BINARY.exists():
         pytest.skip("oracle/_ref/nuts333 was not prebuilt into this snapshot")
     return REF_BINARY
@@ -178,9 +181,16 @@ def test_bench_line_covers_all_five_configs_headline_config4(tmp_path):
     # of the full record written beside it (round 3's 12 KB line lost its load average and restatement leg there)
     assert len(out[0]) <= 6000, len(out[0])
     line, j = json.loads(out[0]), json.loads(record.read_text())
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "cpu_baseline", "warnings",
-              "delivered", "expected_delivered", "configs_all_exact", "extras_errors", "gpu_used"):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "cpu_baseline",
+              "delivered", "expected_delivered", "configs_all_exact", "gpu_used"):
         assert line[k] == j[k], k
+    # free text: what compact_line promises -- counts whole, kept entries cut as documented; on a busy box the
+    # full record may hold more and longer warnings than the line
+    sys.path.insert(0, str(REPO))
+    import bench
+    assert line["warnings_count"] == len(j["warnings"]) and line["extras_errors_count"] == len(j["extras_errors"])
+    assert line["warnings"] in (bench.compact_warnings(j["warnings"], 0), bench.compact_warnings(j["warnings"], 1))
+    assert line["extras_errors"] == bench.compact_errors(j["extras_errors"])
     assert line["roofline"]["frac"] == j["roofline"]["frac"] and line["roofline"]["peak"] == j["roofline"]["peak"]
     assert [(c["name"], c["delivered_lines_per_s"], c["exact"]) for c in line["configs"]] == \
            [(c["name"], c["delivered_lines_per_s"], c["exact"]) for c in j["configs"]]
@@ -192,7 +202,8 @@ def test_bench_line_covers_all_five_configs_headline_config4(tmp_path):
     assert all(c["exact"] for c in j["configs"]) and j["configs_all_exact"] and j["extras_errors"] == []
     assert [c["reps"] for c in j["configs"]] == [3, 3, 3, 3, 3, 1] and [c["n"] for c in j["configs"]] == [1, 10, 100, 100, 1000, 20]
     assert "over 6 rooms" in j["configs"][3]["workload"] and j["configs"][3]["input_lines"] == 20000
-    assert "6 rooms" in line["configs"][3]["workload"] and "note" in line["configs"][2]
+    assert "6 rooms" in line["configs"][3]["workload"]
+    assert "note" in line["configs"][2] or line["warnings_count"] > 0          # (the tight form, many warnings, drops the notes)
     assert j["configs"][5]["netlink"]["exact"] and j["configs"][5]["netlink"]["writes_t2_to_t1"] == 11000
     assert j["host"]["cgroup_throttled_periods_during_run"] in (0, None)
     assert j["configs"][4]["includes_headline_run"] is False          # 500 lines is not the formal 1000: three fresh repetitions
@@ -207,6 +218,21 @@ def test_bench_line_covers_all_five_configs_headline_config4(tmp_path):
     assert 0.85 < r["frac"] <= 1.02 or any(w.startswith("roofline:") for w in j["warnings"]), (r["frac"], demonstrated, j["warnings"])
     assert 0.5 < r["frac"] < 1.5, (r["frac"], demonstrated)          # beyond this no host noise explains it: the harness is broken
     assert j["cpu_baseline"]["kind"] in ("reference", "port") and j["cpu_baseline"]["cores"] == 1
+    # the probe legs explain themselves in the line: rates, CPU/wall, load average; a slow open loop or
+    # a wide spread is named there too
+    for short, leg in (("open", "full_open"), ("closed", "full_closed")):
+        got, src = line["roofline"]["probe_legs"][short], r["probe"][leg]
+        assert got["wall_all"] == src["written_lines_per_s_wall_all"] and got["cpu_over_wall"] in src["cpu_over_wall_all"]
+        assert got["loadavg_before"] is not None and 0 < got["cpu_over_wall"] <= 1.05
+    o_med, c_med = (sorted(r["probe"][k]["written_lines_per_s_wall_all"])[1] for k in ("full_open", "full_closed"))
+    if o_med < 0.9 * c_med:
+        assert any(w.startswith("probe: open-loop") for w in j["warnings"]), j["warnings"]
+    # the as-shipped-flags leg: the -O0 build of the same sources, same workload and size, three times
+    if j["cpu_baseline"]["kind"] == "reference" and REF_BINARY_O0.exists():
+        o0 = j["cpu_baseline_O0"]
+        assert o0["reps"] == 3 and o0["exact"] and len(o0["rate_all_reps"]) == 3 and o0["binary"] == "oracle/_ref/nuts333_O0"
+        assert 0.7 < o0["ratio_to_timed_run"] < 1.15, o0
+        assert line["cpu_baseline_O0"]["value"] == o0["value"] and line["cpu_baseline_O0"]["rate_all_reps"] == o0["rate_all_reps"]
     # the independent second number explains itself: three repetitions, each with its wall clock
     # accounted for, and a ratio to the timed run that is either clean or named in `warnings`
     if j["cpu_baseline"]["kind"] == "reference":

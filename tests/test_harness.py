@@ -61,9 +61,27 @@ def test_config_render_fits_the_parser_limits():
 def test_talker_ports_come_from_below_the_ephemeral_range():
     """A talker's three ports must not be ports the kernel may hand to a client connection as its source port between our
     probe and the talker's bind() (round 4: one "Can't bind to main port: Address already in use" in the suite)."""
-    low = int(Path("/proc/sys/net/ipv4/ip_local_port_range").read_text().split()[0])
+    from nuts333_amd.talker import port_window
+    e_lo, e_hi = (int(x) for x in Path("/proc/sys/net/ipv4/ip_local_port_range").read_text().split()[:2])
+    lo, hi = port_window()
     got = [p for _ in range(50) for p in free_ports(3)]
-    assert len(set(got)) == 150 and all(1024 < p < low for p in got)
+    assert len(set(got)) == 150 and all(lo <= p < hi for p in got)
+    if (e_lo, e_hi) != (1024, 65535):          # (a range covering everything leaves no room outside it)
+        assert all(not e_lo <= p <= e_hi for p in got)
+
+
+def test_port_window_on_hosts_with_a_wide_ephemeral_range():
+    """with ip_local_port_range tuned to start at or below 12000 the window below it was empty or negative
+    (ZeroDivisionError / 'no free ports' at every talker boot).  The window then moves above the range, or stays put."""
+    from nuts333_amd.talker import port_window
+    assert port_window((32768, 60999)) == (12000, 20000)          # the stock range
+    assert port_window((15000, 60999)) == (12000, 15000)          # below it, as long as 1000 ports fit
+    assert port_window((12500, 60999)) == (61000, 65536)          # too little room below: above the top end
+    assert port_window((1024, 60999)) == (61000, 65536)
+    assert port_window((1024, 65535)) == (12000, 20000)           # no room anywhere outside: the plain window, never span <= 0
+    for e in ((32768, 60999), (15000, 60999), (12500, 60999), (1024, 60999), (1024, 65535), (10000, 65000)):
+        lo, hi = port_window(e)
+        assert hi - lo >= 500 and 1024 < lo < hi <= 65536, (e, lo, hi)
 
 
 def test_both_talkers_accept_the_generated_tree(tmp_path, port_binary):
@@ -411,18 +429,38 @@ def _bench(*args, env=None, full=False):
         return j, json.loads(record.read_text())
 
 
+def _assert_compact_free_text(line: dict, full: dict) -> None:
+    """What compact_line PROMISES of the free-text fields: counts exact, the kept entries cut as documented --
+    never `line == full`, which fails on exactly the busy hosts the warnings exist for."""
+    sys.path.insert(0, str(REPO))
+    import bench
+    assert line["warnings_count"] == len(full["warnings"])
+    assert line["warnings"] in (bench.compact_warnings(full["warnings"], 0), bench.compact_warnings(full["warnings"], 1))
+    assert len(line["warnings"]) == min(bench.WARNINGS_KEPT, len(full["warnings"]))
+    if "extras_errors" in full:
+        assert line["extras_errors_count"] == len(full["extras_errors"]) and line["extras_errors"] == bench.compact_errors(full["extras_errors"])
+
+
 def test_bench_single_replica_contract():
     line, j = _bench("--steps", "2", "--warmup", "1", "--lines-per-step", "200", "--binary", "port", "--workload", "config2", full=True)
     assert CONTRACT_KEYS <= set(line) and CONTRACT_KEYS <= set(j)
     # the compact line copies, never recomputes: every figure it carries is the full record's
-    for k in ("value", "ms_per_step", "delivered", "expected_delivered", "cpu_baseline", "warnings", "configs_all_exact", "extras_errors"):
+    for k in ("value", "ms_per_step", "delivered", "expected_delivered", "cpu_baseline", "configs_all_exact"):
         assert line[k] == j[k], k
-    assert {k: v for k, v in line["roofline"].items() if k not in ("note", "unit", "demonstrated_wall_all")} == \
+    _assert_compact_free_text(line, j)
+    assert {k: v for k, v in line["roofline"].items() if k not in ("note", "unit", "probe_legs")} == \
            {k: v for k, v in j["roofline"].items() if k not in ("note", "unit", "probe")}
-    assert line["roofline"]["demonstrated_wall_all"]["open"] == j["roofline"]["probe"]["full_open"]["written_lines_per_s_wall_all"]
+    # VERDICT r4 item 2: each full probe leg explains itself in the line -- rates, CPU/wall of the median repetition, load average
+    for short, leg in (("open", "full_open"), ("closed", "full_closed")):
+        got, src = line["roofline"]["probe_legs"][short], j["roofline"]["probe"][leg]
+        assert got["wall_all"] == src["written_lines_per_s_wall_all"] and len(src["cpu_over_wall_all"]) == 3
+        assert got["cpu_over_wall"] in src["cpu_over_wall_all"] and 0 < got["cpu_over_wall"] <= 1.05
+        assert got["loadavg_before"] == src["loadavg_before"][0]
+    assert "cpu_baseline_O0" not in j          # --binary port: the as-shipped-flags leg belongs to a reference headline
     assert [(c["name"], c["delivered_lines_per_s"], c["exact"], c["rate_all_reps"]) for c in line["configs"]] == \
            [(c["name"], c["delivered_lines_per_s"], c["exact"], c["rate_all_reps"]) for c in j["configs"]]
-    assert line["host"]["loadavg_before_run"] == j["host"]["loadavg_before_run"] and "note" in line["configs"][3]
+    assert line["host"]["loadavg_before_run"] == j["host"]["loadavg_before_run"]
+    assert "note" in line["configs"][3] or len(json.dumps(line)) > 5400          # (notes go first when warnings crowd the line)
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["gpu_used"] is False
     assert j["delivered"] == j["expected_delivered"] == 2 * 200 * 9
     assert j["vs_baseline"] is None and j["scaling"] == "weak" and j["higher_is_better"] is True
@@ -631,6 +669,102 @@ def test_compact_line_fits_the_drivers_tail_even_with_long_warnings():
     assert line["value"] == full["value"] and line["roofline"]["frac"] == full["roofline"]["frac"]
 
 
+def test_line_keeps_one_warning_of_each_kind_before_a_second_of_any():
+    """every stalled repetition adds its own ~500-character warning; six of those used to fill the line's six
+    slots and push the roofline / ratio / client-bound ones out.  Order is kept, lengths are cut, the count is whole."""
+    sys.path.insert(0, str(REPO))
+    import bench
+    stall = [f"config2 repetition {k}: harness stall: " + "y" * 600 for k in range(7)]
+    ws = stall[:5] + ["roofline: the talker ran at only 0.800 ...", "probe: open-loop leg median ...",
+                      "restatement/reference delivered-rate ratio 0.80 outside [0.9, 1.1] ...",
+                      "8 replica(s) under a 16-core quota leave 1 receiver thread each: client-bound by ...",
+                      "config4: repetitions 1 / 2 lines/s spread x2.00 with the talker >= 1.00 busy in each: the core was slower, ..."] + stall[5:]
+    kept = bench.compact_warnings(ws)
+    assert len(kept) == 6 and [bench._warning_kind(w) for w in kept] == ["stall", "roofline", "probe", "ratio", "client-bound", "slow-core"]
+    assert kept[0] == stall[0][:397] + "..." and all(len(w) <= 400 for w in kept)
+    assert all(len(w) <= 160 for w in bench.compact_warnings(ws, tight=1))
+    assert bench.compact_warnings(stall) == [w[:397] + "..." for w in stall[:6]]          # one kind only: the first six, in order
+    assert bench.compact_warnings([]) == []
+    full = json.loads((REPO / "profiles" / "bench_r03_driverargs_run4_final_mi355xhost.json").read_text())
+    line = bench.compact_line({**full, "warnings": ws}, None)
+    assert line["warnings"] == kept and line["warnings_count"] == len(ws) == 12
+
+
+def _probe_leg(walls, ratios, la=9.8):
+    reps = [{"written_lines_per_s_wall": w, "cpu_ns_per_line": 1e12 / w * r, "wall_ns_per_line": 1e12 / w} for w, r in zip(walls, ratios)]
+    med = sorted(reps, key=lambda r: r["written_lines_per_s_wall"])[len(reps) // 2]
+    return {**med, "written_lines_per_s_wall_all": walls, "cpu_over_wall_all": ratios, "loadavg_before": [la, 9.0, 8.0]}
+
+
+def test_probe_legs_explain_themselves_in_the_line():
+    """VERDICT r4 item 2, on the driver's own r04 numbers: open loop 536,647 / 535,873 / 547,691 against closed loop 780,537 /
+    781,169 / 676,750 with `warnings: []` and nothing in the line to tell a waiting probe thread from a slow core.  Both
+    readings of that record, stubbed: the warning names the leg and which reading it was."""
+    sys.path.insert(0, str(REPO))
+    import bench
+    opened, closed = [536647, 535873, 547691], [780537, 781169, 676750]
+
+    def roofline(open_ratios, closed_ratios):
+        return {"probe": {"full_open": _probe_leg(opened, open_ratios), "full_closed": _probe_leg(closed, closed_ratios)}}
+    # (1) the probing thread of the open loop was on its core 0.69 of the time: it waited or was descheduled
+    w = bench.probe_warnings(roofline([0.69, 0.69, 0.70], [0.99, 0.99, 0.86]))
+    assert len(w) == 2 and all(x.startswith("probe:") for x in w)
+    assert "open-loop leg median 536,647" in w[0] and "0.69 x the closed-loop median 780,537" in w[0]
+    assert "only 0.69 of the wall clock" in w[0] and "waited" in w[0] and "descheduled" in w[0]
+    assert "closed-loop leg repetitions 780,537 / 781,169 / 676,750" in w[1] and "spread x1.15" in w[1] and "[0.99, 0.99, 0.86]" in w[1]
+    # (2) same rates, thread busy throughout: the core itself ran slower
+    w = bench.probe_warnings(roofline([0.99, 0.99, 0.99], [0.99, 0.99, 0.99]))
+    assert len(w) == 2 and "busy 0.99 of the wall clock: the core itself ran slower" in w[0] and "open-loop" in w[0]
+    # a clean record (round 4's builder runs: the two legs within 3 %) says nothing
+    clean = {"probe": {"full_open": _probe_leg([782436, 767391, 789645], [0.99] * 3), "full_closed": _probe_leg([771281, 769337, 771759], [0.99] * 3)}}
+    assert bench.probe_warnings(clean) == [] and bench.probe_warnings(None) == []
+    # and the line carries the three fields per leg, inside the budget, on a committed full record of the real shape
+    full = json.loads((REPO / "profiles" / "bench_r04_driverargs_run3_final_mi355xhost_full.json").read_text())
+    rf = roofline([0.69, 0.69, 0.70], [0.99, 0.99, 0.86])
+    full["roofline"]["probe"]["full_open"].update(rf["probe"]["full_open"])
+    full["roofline"]["probe"]["full_closed"].update(rf["probe"]["full_closed"])
+    full["warnings"] = bench.probe_warnings(full["roofline"])
+    full["cpu_baseline_O0"] = {"value": 722017.0, "unit": "lines/s", "cores": 1, "kind": "reference", "binary": "oracle/_ref/nuts333_O0",
+                               "flags": "gcc, no -O flag", "sample": "x", "reps": 3, "exact": True, "rate_all_reps": [722017.0, 725000.1, 719000.2],
+                               "ratio_to_timed_run": 0.96, "server_cpu_us_per_written_line": 1.37, "busy_all_reps": [1.0, 1.0, 1.0]}
+    line = bench.compact_line(full, "gpurun_out/bench_full_n1.json")
+    assert line["roofline"]["probe_legs"]["open"] == {"wall_all": opened, "cpu_over_wall": 0.69, "loadavg_before": 9.8}
+    assert line["roofline"]["probe_legs"]["closed"] == {"wall_all": closed, "cpu_over_wall": 0.99, "loadavg_before": 9.8}
+    assert line["cpu_baseline_O0"]["rate_all_reps"] == [722017.0, 725000.1, 719000.2] and line["cpu_baseline_O0"]["ratio_to_timed_run"] == 0.96
+    assert line["warnings_count"] == 2 and line["warnings"][0].startswith("probe: open-loop")
+    text = bench.render_line(full, "gpurun_out/bench_full_n1.json")          # what main() prints: tight form if need be
+    assert len(text) <= bench.LINE_BUDGET, len(text)
+    printed = json.loads(text)
+    assert printed["roofline"]["probe_legs"] == line["roofline"]["probe_legs"] and printed["warnings_count"] == 2
+    assert "open-loop leg median 536,647" in printed["warnings"][0] and "0.69 x" in printed["warnings"][0]
+    assert len(bench.render_line({**full, "warnings": []}, "gpurun_out/bench_full_n1.json")) <= bench.LINE_BUDGET - 150
+
+
+def test_a_reference_build_that_went_missing_fails_instead_of_skipping(monkeypatch, tmp_path):
+    """build() leaves oracle/_build/ref_built.json when it compiled oracle/_ref/.  Marker present and a
+    binary absent (or changed) = an error everywhere the reference would be used: pick_binary() raises instead of
+    headlining the restatement, and the `ref_binary` fixture / test_gpu_box._binary fail instead of skipping."""
+    import hashlib
+    from nuts333_amd import talker
+    monkeypatch.setattr(talker, "REPO", tmp_path)
+    monkeypatch.setattr(talker, "REF_BINARY", tmp_path / "oracle" / "_ref" / "nuts333")
+    monkeypatch.setattr(workloads, "REF_BINARY", tmp_path / "oracle" / "_ref" / "nuts333")
+    (tmp_path / "oracle" / "_build").mkdir(parents=True)
+    (tmp_path / "oracle" / "_ref").mkdir()
+    assert talker.reference_expected_but_missing() is None          # no marker: a machine without /root/reference, skips are honest
+    blob = b"\x7fELF stand-in bytes"
+    talker.ref_marker().write_text(json.dumps({"sha256": {"nuts333": hashlib.sha256(blob).hexdigest()}}))
+    assert "nuts333 was built for this snapshot, but it is missing" in talker.reference_expected_but_missing()
+    for kind in ("auto", "reference"):
+        with pytest.raises(FileNotFoundError, match="missing"):
+            workloads.pick_binary(kind)
+    assert workloads.pick_binary("port")[1] == "port"          # asking for the restatement by name stays possible
+    (tmp_path / "oracle" / "_ref" / "nuts333").write_bytes(blob)
+    assert talker.reference_expected_but_missing() is None
+    (tmp_path / "oracle" / "_ref" / "nuts333").write_bytes(blob + b"!")
+    assert "differs from the build recorded" in talker.reference_expected_but_missing()
+
+
 def test_every_worker_reports_its_counters_and_its_own_window(port_binary):
     """a receiver thread that got no loop turn between the last delivery and the stop used to report
     cpu_s = 0 (a fabricated 'busy 0.00'); it now samples on its way out, over the window it really covered."""
@@ -642,7 +776,8 @@ def test_every_worker_reports_its_counters_and_its_own_window(port_binary):
 
 def test_placement_tops_up_a_set_too_small_to_hold_the_harness(monkeypatch):
     """a 2-core / 4-thread host.  One thread per core would leave talker + 1 receiver (client-bound) and
-    nothing for config #5's second talker; the set is topped up with the sibling threads, quietest first."""
+    nothing for config #5's second talker; the set is topped up with the sibling threads, quietest first -- except the
+    talker's own sibling (CPU 3 here, talker on CPU 1), which goes last however quiet it is."""
     from nuts333_amd import placement
     cpus = [0, 1, 2, 3]
     monkeypatch.setattr(placement.os, "sched_getaffinity", lambda _pid: set(cpus))
@@ -650,7 +785,7 @@ def test_placement_tops_up_a_set_too_small_to_hold_the_harness(monkeypatch):
     monkeypatch.setattr(placement, "busy_sample", lambda interval=0.25: {0: 0.0, 1: 0.0, 2: 0.5, 3: 0.0})
     monkeypatch.delenv("NUTS_BENCH_CPUS", raising=False)
     got = placement.choose()
-    assert got["policy"] == "quiet" and got["sets"] == [[1, 0, 3, 2]] and "topped up with 2" in got["note"]
+    assert got["policy"] == "quiet" and got["sets"] == [[1, 0, 2, 3]] and "topped up with 2" in got["note"]
 
 
 def test_run_reports_where_the_talkers_wall_clock_went(port_binary):

@@ -31,6 +31,7 @@ print(f"[box] line {len(out.strip())} bytes, whole inside an 8000-byte tail; val
       f"loadavg {j['host']['loadavg_before_run']} restatement x{j['cpu_baseline_port']['ratio_to_timed_run']} "
       f"configs {[c['name'] for c in j['configs']]} exact {j['configs_all_exact']} warnings {j['warnings']}")
 PY
+[ $? -eq 0 ] || { echo "[box] the line is not whole in the 8000-byte tail (or is not JSON)"; exit 1; }
 echo "[box] bench (driver args) ok"
 fi
 if [ "$STAGE" = more ]; then

@@ -84,8 +84,8 @@ def salvage(tail: str, parsed: dict) -> dict:
 
 def record() -> str:
     """Section 0: the driver-run lines, one row per round (the number of record is the driver's)."""
-    rows = ["| Driver file | command | headline workload | **delivered lines/s** | ms/step | host load average | `roofline.frac` as printed | vs demonstrated peak | vs CPU-time extrapolation | restatement leg (`cpu_baseline_port`) | configs medians #1 input/s · #2 · #3 (· #3 with six rooms, from round 4) · #4 · #5 |",
-            "|---|---|---|---|---|---|---|---|---|---|---|"]
+    rows = ["| Driver file | command | headline workload | **delivered lines/s** | ms/step | host load average | `roofline.frac` as printed | vs demonstrated peak | vs CPU-time extrapolation | restatement leg (`cpu_baseline_port`) | as-shipped flags: `-O0` build (`cpu_baseline_O0`, from round 5) | configs medians #1 input/s · #2 · #3 (· #3 with six rooms, from round 4) · #4 · #5 |",
+            "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for name, rec, j in driver_lines():
         rf = j.get("roofline") or {}
         probe = rf.get("probe") or {}
@@ -104,6 +104,9 @@ def record() -> str:
         rows[-1] += (f"{port['value']:,.0f} (×{ratio:.2f} of the timed run"
                      + (f", {port['server_cpu_us_per_written_line']} µs/line" if port.get("server_cpu_us_per_written_line") else "")
                      + (f"; {port['salvaged']}" if port.get("salvaged") else "") + ")" if port.get("value") else "—")
+        o0 = j.get("cpu_baseline_O0") or {}
+        rows[-1] += " | " + (f"{o0['value']:,.0f} (×{o0['ratio_to_timed_run']:.2f} of the timed run, {o0.get('server_cpu_us_per_written_line', '?')} µs/line; "
+                             f"{' · '.join(f'{x:,.0f}' for x in o0.get('rate_all_reps', []))})" if o0.get("value") else "—")
         rows[-1] += " | " + (" · ".join(f"{cs[k]:,.0f}" for k in ("config1", "config2", "config3", "config3_six_rooms", "config4", "config5") if k in cs) or "—") + " |"
     if len(rows) == 2:
         return ""
@@ -111,6 +114,17 @@ def record() -> str:
     for name, rec, j in driver_lines():
         for w in j.get("warnings") or []:
             notes.append(f"* `{name}` warning: {w}")
+        rf = j.get("roofline") or {}
+        legs = rf.get("probe_legs") or {k: {"wall_all": v} for k, v in (rf.get("demonstrated_wall_all") or {}).items()}
+        if legs.get("open") and legs.get("closed"):
+            o, c = sorted(legs["open"]["wall_all"])[len(legs["open"]["wall_all"]) // 2], sorted(legs["closed"]["wall_all"])[len(legs["closed"]["wall_all"]) // 2]
+            how = ("; CPU/wall of the probing thread " + " / ".join(f"{k} {legs[k].get('cpu_over_wall')}" for k in ("open", "closed"))
+                   + f", load average {legs['open'].get('loadavg_before')}") if "cpu_over_wall" in legs["open"] else \
+                  "; the line of that round kept no CPU/wall figure per probe leg, so the cause cannot be read from the record"
+            if o < 0.9 * c or any(max(l["wall_all"]) / min(l["wall_all"]) > 1.15 for l in (legs["open"], legs["closed"])):
+                notes.append(f"* `{name}` probe legs: open loop {' / '.join(f'{x:,.0f}' for x in legs['open']['wall_all'])}, closed loop "
+                             f"{' / '.join(f'{x:,.0f}' for x in legs['closed']['wall_all'])} lines/s — open-loop median {o / c:.2f} × the closed-loop median{how} "
+                             f"(`DESIGN.md` §10; `peak` is the max over the six and was a clean closed-loop repetition)")
     return ("## 0. Numbers of record — the driver's own runs of `bench.py` on a fresh MI355X box\n\n"
             "Generated by `tools/refresh_baseline_md.py` from the `BENCH_rNN.json` files the driver leaves at the repository root. Where a builder-run\n"
             "figure elsewhere in this file or in `DESIGN.md` differs, **these are the numbers of record**; the builder's runs on other allocations of the\n"
@@ -122,7 +136,11 @@ def record() -> str:
             "round 2's reading stays undetermined and the item is closed (`DESIGN.md` §10). `BENCH_r03.json` holds only the last ~8 KB of a 12 KB\n"
             "line, so its load average, restatement leg and configs above are read out of that cut tail (`salvage()` in the generator; nothing is\n"
             "guessed, the entry says what was visible). From round 4 the line printed on stdout is a compact record under 6 KB that the driver's\n"
-            "tail keeps whole; the full record goes to `gpurun_out/bench_full_n<N>.json`.\n")
+            "tail keeps whole; the full record goes to `gpurun_out/bench_full_n<N>.json`, which only builder-run `gpurun` calls bring back (the\n"
+            "driver's bench pull is `n1.out`/`n1.err`/`n1.wall` + `smi.*`). From round 5 the line therefore carries, per probe leg, every\n"
+            "repetition's rate, the CPU/wall ratio of the probing thread and the load average (`roofline.probe_legs`), a `probe:` warning when the\n"
+            "open loop reads below 0.9 × the closed one or a leg spreads more than ×1.15, and `cpu_baseline_O0`: the headline workload on the\n"
+            "reference compiled with its own build script's flags (no `-O`, `/root/reference/build:7,15`).\n")
 
 
 def round2() -> str:
