@@ -377,8 +377,12 @@ def _short(text: str, n: int) -> str:
     return text if len(text) <= n else text[:n - 3] + "..."
 
 
-#: how many warnings / extras errors the line keeps, and how long each may be (normal, tight)
-WARNINGS_KEPT, WARNING_LEN, ERRORS_KEPT, ERROR_LEN = 6, (400, 160), 6, 300
+#: how many warnings / extras errors the line keeps, and how long each may be at each ``tight`` level (0 = normal).  Level 2
+#: and 3 exist because round 5's new fields (``probe_legs``, ``cpu_baseline_O0``) used up the headroom: five or six long
+#: warnings of distinct kinds put the level-1 line at 6.1-6.3 KB.  The count beside them is always whole and
+#: the full record holds every one uncut.
+WARNINGS_KEPT, WARNING_LEN, ERRORS_KEPT, ERROR_LEN = 6, (400, 160, 100, 60), 6, (300, 300, 120, 80)
+TIGHT_LEVELS = tuple(range(len(WARNING_LEN)))
 
 
 def _warning_kind(w: str) -> str:
@@ -411,11 +415,11 @@ def compact_warnings(warnings: list[str], tight: int = 0) -> list[str]:
             first.append(i)
     rest = [i for i in range(len(warnings)) if i not in set(first)]
     keep = sorted((first + rest)[:WARNINGS_KEPT])
-    return [_short(warnings[i], WARNING_LEN[1 if tight else 0]) for i in keep]
+    return [_short(warnings[i], WARNING_LEN[min(tight, TIGHT_LEVELS[-1])]) for i in keep]
 
 
-def compact_errors(errors: list[str]) -> list[str]:
-    return [_short(e, ERROR_LEN) for e in errors[:ERRORS_KEPT]]
+def compact_errors(errors: list[str], tight: int = 0) -> list[str]:
+    return [_short(e, ERROR_LEN[min(tight, TIGHT_LEVELS[-1])]) for e in errors[:ERRORS_KEPT]]
 
 
 def compact_line(full: dict, full_record: str | None, *, tight: int = 0) -> dict:
@@ -423,8 +427,10 @@ def compact_line(full: dict, full_record: str | None, *, tight: int = 0) -> dict
     exactness, the warnings as ``compact_warnings`` keeps them (count beside them) -- and none of the per-repetition
     counters (those are in the full record).  Nothing here is recomputed: each value is copied from ``full``.
     ``tight`` > 0 (a line still over LINE_BUDGET, i.e. many long warnings) shortens the free-text fields further, never
-    the figures."""
-    notes = tight == 0
+    the figures: 1 drops the per-configuration notes and cuts warnings to 160 characters; 2 also drops the other prose that
+    only repeats what DESIGN.md says (``roofline.peak_source`` / ``note``, the -O0 leg's ``flags``, the configurations'
+    ``workload`` strings) and cuts warnings to 100 and errors to 120; 3 cuts them to 60 and 80."""
+    notes, prose = tight == 0, tight < 2
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "gpu_used", "classification", "delivered", "expected_delivered", "input_lines_per_s",
             "ack_latency_us", "server_cpu_us_per_written_line", "server_busy_frac", "server_syscalls", "configs_all_exact")
@@ -447,7 +453,10 @@ def compact_line(full: dict, full_record: str | None, *, tight: int = 0) -> dict
     if o0:
         c["cpu_baseline_O0"] = {k: o0[k] for k in ("value", "kind", "flags", "reps", "exact", "rate_all_reps", "ratio_to_timed_run",
                                                    "server_cpu_us_per_written_line")}
-        c["cpu_baseline_O0"]["flags"] = "no -O flag (reference/build:7,15)"
+        if prose:
+            c["cpu_baseline_O0"]["flags"] = "no -O flag (reference/build:7,15)"
+        else:
+            del c["cpu_baseline_O0"]["flags"]
     if "configs" in full:
         c["configs"] = []
         for e in full["configs"]:
@@ -455,7 +464,7 @@ def compact_line(full: dict, full_record: str | None, *, tight: int = 0) -> dict
                                     "reps", "rate_all_reps", "server_busy_frac", "error") if k in e}
             if e.get("includes_headline_run"):          # (absent = false: three fresh repetitions)
                 ce["includes_headline_run"] = True
-            if "workload" in e:
+            if "workload" in e and prose:
                 ce["workload"] = _short(e["workload"].split(": ", 1)[-1], 80)
             if "netlink" in e:
                 ce["netlink"] = {k: e["netlink"][k] for k in ("writes_t1_to_t2", "writes_t2_to_t1", "exact") if k in e["netlink"]}
@@ -467,18 +476,19 @@ def compact_line(full: dict, full_record: str | None, *, tight: int = 0) -> dict
         c["device_floor"] = {k: f[k] for k in ("kernel_launch_plus_sync_us", "graph_replay_plus_sync_us", "h2d_64B_kernel_d2h_69KB_sync_us")
                              if k in f} if f else None
     if "extras_errors" in full:
-        c["extras_errors"] = compact_errors(full["extras_errors"])
+        c["extras_errors"] = compact_errors(full["extras_errors"], tight)
         c["extras_errors_count"] = len(full["extras_errors"])
     c["warnings"] = compact_warnings(full["warnings"], tight)
     c["warnings_count"] = len(full["warnings"])
     c["full_record"] = full_record
     r = full.get("roofline")
     if r:
-        c["roofline"] = {k: v for k, v in r.items() if k not in ("probe", "note", "unit")}
+        c["roofline"] = {k: v for k, v in r.items() if k not in ("probe", "note", "unit") and (prose or k != "peak_source")}
         c["roofline"]["unit"] = "lines written/s on one core"
         c["roofline"]["probe_legs"] = {"open": probe_leg_summary(r["probe"]["full_open"]),
                                        "closed": probe_leg_summary(r["probe"]["full_closed"])}
-        c["roofline"]["note"] = "host system-call ceiling; no HBM/MFMA roofline applies: no device kernel exists"
+        if prose:
+            c["roofline"]["note"] = "host system-call ceiling; no HBM/MFMA roofline applies: no device kernel exists"
     else:
         c["roofline"] = None
     c["cpu_baseline"] = full["cpu_baseline"]
@@ -486,10 +496,11 @@ def compact_line(full: dict, full_record: str | None, *, tight: int = 0) -> dict
 
 
 def render_line(full: dict, full_record: str | None) -> str:
-    """The stdout line: the compact record, in ``tight`` form when the normal one would exceed LINE_BUDGET."""
-    line = json.dumps(compact_line(full, full_record))
-    if len(line) > LINE_BUDGET:
-        line = json.dumps(compact_line(full, full_record, tight=1))
+    """The stdout line: the compact record, at the first ``tight`` level that fits LINE_BUDGET."""
+    for tight in TIGHT_LEVELS:
+        line = json.dumps(compact_line(full, full_record, tight=tight))
+        if len(line) <= LINE_BUDGET:
+            break
     if len(line) > LINE_BUDGET:
         print(f"[bench] WARNING: the line is {len(line)} bytes, over the {LINE_BUDGET}-byte budget the driver's tail keeps", file=sys.stderr, flush=True)
     return line
@@ -840,8 +851,13 @@ def main() -> int:
         print(render_line(out, write_full_record(out, world)))
     if dist is not None:
         dist.destroy_process_group()
-    for w in warnings:
+    # stderr shares the driver's ~8 KB tail with the line (its record is stdout + "---- stderr ----" + stderr, cut from the
+    # front): echo what the line keeps, in the 160-character form, not every warning whole -- six 500-character
+    # warnings whole were 3 KB and pushed the head of the line out of the record again.  The full record has them uncut.
+    for w in compact_warnings(warnings, 1):
         print(f"[bench] WARNING: {w}", file=sys.stderr, flush=True)
+    if len(warnings) > WARNINGS_KEPT:
+        print(f"[bench] ... and {len(warnings) - WARNINGS_KEPT} more warning(s); every one whole in the full record", file=sys.stderr, flush=True)
     # the line is always printed; the exit code says whether the record in it is exact
     if not out.get("configs_all_exact", True):
         print("[bench] FAILED: not every configuration in `configs` completed exactly -- see the line", file=sys.stderr, flush=True)
