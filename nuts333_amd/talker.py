@@ -108,13 +108,42 @@ def ref_marker() -> Path:
     return REPO / "oracle" / "_build" / "ref_built.json"
 
 
+#: where the reference's sources are when they are anywhere (the build container); never present on the GPU box
+REFERENCE_TREE = Path("/root/reference")
+#: the kernel's compute device node: present on a GPU box (reading the path touches no GPU), absent in the build container
+KFD_NODE = Path("/dev/kfd")
+
+
+def reference_required() -> str | None:
+    """the marker and the binaries it vouches for are both git-ignored artefacts and travel together; a snapshot
+    that drops ignored files wholesale loses both, and the absence of the marker then reads as "a machine that never had the
+    reference" -- skips with rc 0, the restatement in the headline.  So the expectation also lives where the artefacts do
+    not: ``NUTS_REQUIRE_REFERENCE=1`` (set by tools/box_r06.sh) demands the reference binary, ``=0`` waives it, and with
+    neither set a machine that HAS a GPU device node and has NO /root/reference is taken to be the GPU box, which can only
+    ever run the reference if the snapshot carried it.  Returns why it is required, or None."""
+    env = os.environ.get("NUTS_REQUIRE_REFERENCE", "").strip()
+    if env == "0":
+        return None
+    if env:
+        return f"NUTS_REQUIRE_REFERENCE={env} is set"
+    if KFD_NODE.exists() and not REFERENCE_TREE.exists():
+        return (f"this machine has {KFD_NODE} and no {REFERENCE_TREE} (a GPU box: the snapshot is expected to carry the prebuilt "
+                f"oracle/_ref/; NUTS_REQUIRE_REFERENCE=0 waives this)")
+    return None
+
+
 def reference_expected_but_missing() -> str | None:
     """the marker says a reference build was made for this snapshot; if a binary it names is absent
-    or differs, say so -- callers FAIL on it instead of skipping (tests) or headlining the restatement (bench.py)."""
+    or differs, say so -- callers FAIL on it instead of skipping (tests) or headlining the restatement (bench.py).
+    Without a marker the same holds when ``reference_required()`` says the reference must be here."""
     import hashlib
     import json
     m = ref_marker()
     if not m.exists():
+        why = reference_required()
+        if why and not REF_BINARY.exists():
+            return (f"oracle/_ref/{REF_BINARY.name} is missing, and so is the marker oracle/_build/ref_built.json, but {why}: the snapshot "
+                    f"lost its prebuilt artefacts -- rebuild with __graft_entry__.build() where /root/reference exists")
         return None
     try:
         want = json.loads(m.read_text())["sha256"]

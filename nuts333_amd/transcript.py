@@ -216,15 +216,22 @@ class Session:
     # -- plumbing ----------------------------------------------------------------------
     #: the talker's own replies to a toggle of ignall (toggle_ignall, nuts333.c:4463-4476)
     _IGNALL_ON, _IGNALL_OFF = b"You are now ignoring everyone.", b"You will now hear everyone again."
+    #: either reply as the talker writes it to the user who toggled: a whole line (write_user turns "\n" into "\n\r", with
+    #: ESC[0m before it when colour is on, nuts333.c:1326-1334), at the start of the capture, after a line end, or directly
+    #: after the command-mode prompt "COM> " / "COM+> " (nuts333.c:2185-2189), which ends in no newline
+    _IGNALL_REPLY = re.compile(rb"(?:\A|[\r\n]|COM\+?> (?:\x1b\[0m)?)(" + re.escape(_IGNALL_ON) + rb"|" + re.escape(_IGNALL_OFF) + rb")(?:\x1b\[0m)?\n")
 
     def _record(self, what: dict, recv: dict[str, bytes]) -> None:
         # hears_broadcasts follows what the TALKER said, not what was typed: an abbreviated command toggles too,
         # a level-gated refusal does not; the later of the two replies in a capture wins.  Only close()'s wait reads the flag.
-        for k, v in recv.items():
-            c = self.clients.get(k)
-            on, off = v.rfind(self._IGNALL_ON), v.rfind(self._IGNALL_OFF)
-            if c is not None and max(on, off) >= 0:
-                c.hears_broadcasts = off > on
+        # Only the ACTOR's own capture of the step is read, and only a reply that is a whole line: toggle_ignall
+        # answers the user who typed it (nuts333.c:4467,4473), so the same words inside somebody's .say -- the speaker's
+        # "You say: ..." echo, a listener's copy -- are payload, not a reply.
+        c = self.clients.get(what.get("actor"))
+        if c is not None:
+            replies = self._IGNALL_REPLY.findall(recv.get(c.key, b""))
+            if replies:
+                c.hears_broadcasts = replies[-1] == self._IGNALL_OFF
         self.steps.append({**what, "recv": {k: normalise(v).decode("latin-1") for k, v in recv.items() if v}})
 
     def _sync(self, c: Client) -> bytes:
@@ -486,7 +493,9 @@ class Session:
         expect_broadcast = bool(listeners) and c.logged_in
         deadline = time.monotonic() + (5.0 if expect_broadcast else 0.5)
         seen = False
-        if not listeners and others:          # nobody who could be sent the broadcast: the short wait, passive, nothing to look for
+        if not listeners and others and c.logged_in:
+            # a logged-in leaver whom nobody can be sent: the short wait, passive, nothing to look for.  A half-open login
+            # leaves without a word to anyone (nuts333.c:1770-1775) and nobody is waited on: no sleep at all
             time.sleep(max(0.0, deadline - time.monotonic()))
         while listeners and not seen and time.monotonic() < deadline:
             ready, _, _ = select.select(listeners, [], [], max(0.0, deadline - time.monotonic()))

@@ -66,8 +66,13 @@ def test_talker_ports_come_from_below_the_ephemeral_range():
     lo, hi = port_window()
     got = [p for _ in range(50) for p in free_ports(3)]
     assert len(set(got)) == 150 and all(lo <= p < hi for p in got)
-    if (e_lo, e_hi) != (1024, 65535):          # (a range covering everything leaves no room outside it)
+    # the exemption is port_window's own: when the window it returns lies outside the ephemeral range no drawn
+    # port may be inside it; when the host's range leaves no 1000 ports on either side -- (1024, 65535), but also e.g.
+    # (10000, 65000) -- the documented fallback 12000-20000 intersects the range and there is nothing to assert
+    if hi <= e_lo or lo > e_hi:
         assert all(not e_lo <= p <= e_hi for p in got)
+    else:
+        assert (lo, hi) == (12000, 20000) and min(20000, e_lo) - 12000 < 1000 and 65535 - e_hi < 1000, (lo, hi, e_lo, e_hi)
 
 
 def test_port_window_on_hosts_with_a_wide_ephemeral_range():
@@ -112,8 +117,16 @@ def test_close_does_not_wait_for_a_broadcast_nobody_will_be_sent(tmp_path, port_
         try:
             for k, n in (("a", "Alice"), ("b", "Bobby")):
                 s.connect(k); s.login(k, n)
+            # the toggle's words as PAYLOAD flip nothing -- not in the speaker's own "You say:" echo, not in the
+            # listener's copy; only the talker's reply to the user who toggled, as a whole line, does
+            s.line("a", "You are now ignoring everyone.")
+            assert "says: You are now ignoring everyone." in s.steps[-1]["recv"]["b"]
+            assert s.clients["a"].hears_broadcasts is True and s.clients["b"].hears_broadcasts is True
             s.line("b", ".ignall")
             assert s.clients["b"].hears_broadcasts is False
+            s.line("b", "You will now hear everyone again.")
+            assert "You say: You will now hear everyone again." in s.steps[-1]["recv"]["b"]
+            assert s.clients["b"].hears_broadcasts is False and s.clients["a"].hears_broadcasts is True
             t = time.monotonic()
             s.close("a")
             assert time.monotonic() - t < 2.5 and "SIGN OFF" not in s.steps[-1]["recv"].get("b", "")
@@ -709,6 +722,33 @@ def test_line_with_round5_fields_and_a_full_set_of_long_warnings_still_fits():
     assert echo <= bench.WARNINGS_KEPT * 180 and len(text) + echo + 600 <= 8000
 
 
+def test_as_shipped_flags_leg_cannot_go_wrong_in_silence(monkeypatch):
+    """the -O0 leg was the only one whose ratio or exactness could be off without a warning or an exit code.
+    Stubbed talker runs: in the band nothing is said; outside it the line names the ratio (same kind as the restatement
+    leg's sentence, so it shares that slot); an inexact repetition is named and `exact` is false (main() exits 1 on it)."""
+    sys.path.insert(0, str(REPO))
+    import bench
+
+    def run(rate, exact=True, cpu=1.41):
+        return {"delivered_lines_per_s": rate, "exact": exact, "input_lines": 2000, "deliveries": 1998000,
+                "servers": [{"cpu_us_per_written_line": cpu, "busy_frac": 1.0}]}
+    timed = run(750000.0, cpu=1.32)
+    monkeypatch.setattr(bench, "leg_report", lambda *a, **k: {})
+    monkeypatch.setattr(bench, "measured", lambda fn: (fn(), {}))
+
+    def leg(results):
+        it, warnings = iter(results), []
+        monkeypatch.setattr(bench, "run_workload", lambda *a, **k: next(it))
+        return bench.as_shipped_flags_leg("config4", 2500, 500, False, timed, lambda what, fn: fn(), warnings), warnings
+    o0, w = leg([run(705000.0), run(712000.0), run(690000.0)])
+    assert o0["ratio_to_timed_run"] == 0.94 and o0["exact"] and w == []
+    o0, w = leg([run(150000.0), run(140000.0), run(705000.0)])                    # two stalled repetitions: median 150 k
+    assert o0["ratio_to_timed_run"] == 0.2 and len(w) == 1 and w[0].startswith("-O0 build/reference delivered-rate ratio 0.20 outside [0.85, 1.05]")
+    assert "150,000 / 140,000 / 705,000" in w[0] and "stalls above" in w[0] and bench._warning_kind(w[0]) == "ratio"
+    o0, w = leg([run(705000.0), run(712000.0, exact=False), run(690000.0)])
+    assert o0["exact"] is False and len(w) == 1 and "cpu_baseline_O0.exact is false" in w[0] and bench._warning_kind(w[0]) == "ratio"
+
+
 def test_line_keeps_one_warning_of_each_kind_before_a_second_of_any():
     """every stalled repetition adds its own ~500-character warning; six of those used to fill the line's six
     slots and push the roofline / ratio / client-bound ones out.  Order is kept, lengths are cut, the count is whole."""
@@ -791,7 +831,26 @@ def test_a_reference_build_that_went_missing_fails_instead_of_skipping(monkeypat
     monkeypatch.setattr(workloads, "REF_BINARY", tmp_path / "oracle" / "_ref" / "nuts333")
     (tmp_path / "oracle" / "_build").mkdir(parents=True)
     (tmp_path / "oracle" / "_ref").mkdir()
+    monkeypatch.delenv("NUTS_REQUIRE_REFERENCE", raising=False)
+    monkeypatch.setattr(talker, "KFD_NODE", tmp_path / "no-such-device-node")
     assert talker.reference_expected_but_missing() is None          # no marker: a machine without /root/reference, skips are honest
+    # marker AND binaries lost together (a snapshot that dropped every ignored file).  The expectation then comes
+    # from outside the artefacts: the box scripts' env flag, or the machine being a GPU box (device node, no reference tree).
+    monkeypatch.setenv("NUTS_REQUIRE_REFERENCE", "1")
+    assert "lost its prebuilt artefacts" in talker.reference_expected_but_missing() and "NUTS_REQUIRE_REFERENCE=1" in talker.reference_expected_but_missing()
+    with pytest.raises(FileNotFoundError, match="lost its prebuilt artefacts"):
+        workloads.pick_binary("auto")
+    monkeypatch.delenv("NUTS_REQUIRE_REFERENCE")
+    (tmp_path / "kfd").write_text("")
+    monkeypatch.setattr(talker, "KFD_NODE", tmp_path / "kfd")
+    monkeypatch.setattr(talker, "REFERENCE_TREE", tmp_path / "no-reference-tree-here")
+    assert "a GPU box" in talker.reference_expected_but_missing()
+    monkeypatch.setenv("NUTS_REQUIRE_REFERENCE", "0")                 # waived by name
+    assert talker.reference_expected_but_missing() is None and workloads.pick_binary("auto")[1] == "port"
+    monkeypatch.delenv("NUTS_REQUIRE_REFERENCE")
+    monkeypatch.setattr(talker, "REFERENCE_TREE", tmp_path)          # a GPU machine that has the sources can build: nothing demanded
+    assert talker.reference_expected_but_missing() is None
+    monkeypatch.setattr(talker, "KFD_NODE", tmp_path / "no-such-device-node")
     blob = b"\x7fELF stand-in bytes"
     talker.ref_marker().write_text(json.dumps({"sha256": {"nuts333": hashlib.sha256(blob).hexdigest()}}))
     assert "nuts333 was built for this snapshot, but it is missing" in talker.reference_expected_but_missing()
